@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Headline benchmark: agent updates/sec of DrQV2Agent.update() (HIP path) on synthetic, device-resident
+replay batches.  Contract: python bench.py --gpus N --steps K --warmup W  ->  ONE JSON line on rank 0.
+
+  step      = one DrQV2Agent.update(): aug x2, encoder fwd x2, critic loss+backward, Adam(critic, encoder),
+              actor loss+backward, Adam(actor), Polyak; metrics fetched (use_tb=True) every update.
+  workload  = BASELINE.json configs[1]: cheetah_run, batch_size=256, 9x84x84 uint8 observations, A=6,
+              feature_dim=50, hidden_dim=1024, fp32.  N>1: one process per GPU (torch.distributed, RCCL),
+              every rank trains on its own 256-sample shard (weak scaling; --strong splits ONE 256 batch)
+              with two gradient all-reduces per update; value = batch-256 updates/sec of the whole job
+              = global samples/sec / 256.
+  roofline  = dominant kernel conv3x3_kernel<32,41,1> (conv2 forward on both views + conv3 dgrad),
+              timed live with events on the launch stream; algorithmic FLOPs = 2*32*288 per output pixel.
+  cpu_baseline = the CPU oracle (oracle/drq_oracle.py, kind "port") on the host cores, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TASKS = {   # name: (A, feature_dim, lr, stddev_schedule)  -- cfgs/task/*.yaml of the reference
+    "cheetah_run": (6, 50, 1e-4, "linear(1.0,0.1,500000)"),
+    "quadruped_walk": (12, 50, 1e-4, "linear(1.0,0.1,500000)"),
+    "humanoid_run": (21, 100, 8e-5, "linear(1.0,0.1,2000000)"),
+    "cartpole_swingup": (1, 50, 1e-4, "linear(1.0,0.1,100000)"),
+}
+PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32 matrix == vector peak
+
+
+def alg_flops_per_update(B, A, F, H=1024):
+    """F_alg = B*[2*E_f + E_b + 8T + 4P + 12Q]."""
+    E_f, E_b = 84_561_984, 160_409_664
+    T = 2 * 39200 * F
+    P = 2 * (F * H + H * H + H * A)
+    Q = 2 * ((F + A) * H + H * H + H)
+    return B * (2 * E_f + E_b + 8 * T + 4 * P + 12 * Q)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak) or global batch (--strong)")
+    ap.add_argument("--task", default="cheetah_run", choices=list(TASKS))
+    ap.add_argument("--strong", action="store_true", help="split ONE --batch over the GPUs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import drqv2
+    from drqv2_amd import synth
+
+    A, F, lr, sched = TASKS[args.task]
+    H = 1024
+    B_local = args.batch // world if args.strong else args.batch
+    B_global = B_local * world
+    torch.manual_seed(1)
+    agent = drqv2.DrQV2Agent((9, 84, 84), (A,), dev, lr, F, H, 0.01, 2000, 2, sched, 0.3, True)
+    if world > 1:
+        agent.enable_data_parallel(batch_is_global=False)
+    batch = tuple(t.to(dev) for t in synth.make_batch(B_local, A, 9, seed=rank, smooth=True))
+
+    def replay():
+        while True:
+            yield batch
+
+    it = replay()
+    step = 0
+    for _ in range(args.warmup):
+        agent.update(it, step)
+        step += 2
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        metrics = agent.update(it, step)
+        step += 2
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    value = args.steps * (B_global / 256.0) / dt
+    out = {
+        "metric": "agent updates/sec (batch=256, 9x84x84 obs)", "value": value, "unit": "updates/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.task} batch_size={B_local}/GPU ({B_global} global) 9x84x84 u8 obs, A={A}, "
+                               f"feature_dim={F}, hidden_dim={H}, fp32, use_tb=True",
+                   "parallelism": f"dp{world}", "global_batch": B_global},
+        "alg_gflop_per_update": alg_flops_per_update(B_global, A, F, H) / 1e9,
+        "frac_fp32_peak_whole_step": alg_flops_per_update(B_global, A, F, H) * args.steps / dt /
+                                     (PEAK_FP32_TFLOPS * 1e12 * world),
+        "last_metrics": metrics,
+    }
+
+    if rank == 0 and not args.no_roofline:
+        out["roofline"] = roofline_conv(agent, B_local)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.task, B_local)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def roofline_conv(agent, B):
+    """conv3x3_kernel<32,41,1>: its two launches per update (conv2 forward on 2B frames, conv3 dgrad on B),
+    timed with events on the stream they are launched on (torch's current stream)."""
+    from drqv2_amd import ops
+    eng = agent._engine
+    act1 = eng.ws_view("ACT1", B, (2 * B, 32, 41, 41))
+    dy3 = eng.ws_view("DY3", B, (B, 32, 41, 41))
+    act2 = eng.ws_view("ACT2", B, (2 * B, 32, 39, 39))[:B]
+    w = agent.encoder.convnet[2].weight.data
+    b = agent.encoder.convnet[2].bias.data
+    w3 = agent.encoder.convnet[4].weight.data
+    reps = 20
+    for _ in range(3):
+        ops.conv3x3_fwd(act1, w, b, 1)
+        ops.conv3x3_dgrad(dy3, w3, act2)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * reps + 1)]
+    ev[0].record()
+    for i in range(reps):
+        ops.conv3x3_fwd(act1, w, b, 1)
+        ev[2 * i + 1].record()
+        ops.conv3x3_dgrad(dy3, w3, act2)
+        ev[2 * i + 2].record()
+    torch.cuda.synchronize()
+    t_f = sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(reps)) / reps * 1e-3
+    t_d = sum(ev[2 * i + 1].elapsed_time(ev[2 * i + 2]) for i in range(reps)) / reps * 1e-3
+    fl_f = 2 * 32 * 288 * (2 * B) * 39 * 39
+    fl_d = 2 * 32 * 288 * B * 39 * 39
+    ach = (fl_f + fl_d) / (t_f + t_d) / 1e12
+    return {"kernel": "conv3x3_kernel<32,41,1>", "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS,
+            "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "traffic": None,
+            "avg_launch_us": 0.5e6 * (t_f + t_d), "launch_us": {"conv2_fwd_2B": 1e6 * t_f, "conv3_dgrad_B": 1e6 * t_d},
+            "alg_gflop_per_launch": {"conv2_fwd_2B": fl_f / 1e9, "conv3_dgrad_B": fl_d / 1e9}}
+
+
+def cpu_baseline(task, B):
+    """The CPU oracle timed on the host cores: same workload, bounded sample (2 warm-up + 4 timed updates)."""
+    from drqv2_amd import synth
+    from oracle import drq_oracle as O
+    A, F, lr, sched = TASKS[task]
+    torch.set_num_threads(os.cpu_count() or 1)
+    enc, actor, critic = synth.make_weights(9, A, F, 1024, 0)
+    ag = O.OracleAgent(enc, actor, critic, lr, stddev_schedule=sched)
+    batch = synth.make_batch(B, A, 9, seed=0, smooth=True)
+    draws = synth.make_draws(B, A, seed=0)
+    ts = []
+    for u in range(6):
+        t0 = time.perf_counter()
+        ag.update(batch, 2 * u, *draws)
+        ts.append(time.perf_counter() - t0)
+    ts = sorted(ts[2:])
+    med = 0.5 * (ts[1] + ts[2])
+    return {"value": 1.0 / med, "unit": "updates/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/drq_oracle.py OracleAgent.update, {task} B={B} fp32, 2 warm-up + 4 timed updates, median"}
+
+
+if __name__ == "__main__":
+    main()

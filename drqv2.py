@@ -1,0 +1,247 @@
+"""Drop-in `drqv2` module: the Hydra target `drqv2.DrQV2Agent` (cfgs/config.yaml:35 of the reference)
+with the reference's constructor surface, backed by the MI355X HIP library (libdrqv2_hip.so).
+
+Reference: /root/reference/drqv2.py.  Parity contract (tests/):
+  * constructors keep names, argument order, sub-module names and state_dict keys
+    (convnet.{0,2,4,6}, trunk.{0,1}, policy.{0,2,4}, Q{1,2}.{0,2,4}) and consume the global torch
+    RNG exactly like the reference (same nn layers built in the same order, same init);
+  * update() issues the four random draws of the reference in its order (drqv2.py:34-38 twice,
+    utils.py:119 twice) and runs aug -> encoder -> critic step -> actor step -> target update in
+    hand-written HIP kernels; there is no PyTorch/CPU fallback for that path;
+  * metrics: the same 8 keys as python floats when use_tb, {} on gated-off steps.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+import utils
+from drqv2_amd import _lib, ops
+from drqv2_amd.engine import StepEngine
+from torch.distributions.utils import _standard_normal
+
+
+class RandomShiftsAug(nn.Module):
+    """Random shift by up to `pad` pixels: replicate pad + bilinear resample (drqv2.py:14-45)."""
+
+    def __init__(self, pad):
+        super().__init__()
+        self.pad = pad
+
+    def draw(self, n, device, dtype=torch.float32):
+        # identical call to drqv2.py:34-38 -> identical shifts under the same seed/device
+        return torch.randint(0, 2 * self.pad + 1, size=(n, 1, 1, 2), device=device, dtype=dtype)
+
+    def forward(self, x):
+        n, c, h, w = x.size()
+        assert h == w
+        shift = self.draw(n, x.device, torch.float32)
+        return ops.random_shifts_aug(x.contiguous(), shift, self.pad)
+
+
+class Encoder(nn.Module):
+    def __init__(self, obs_shape):
+        super().__init__()
+        assert len(obs_shape) == 3
+        self.repr_dim = 32 * 35 * 35
+        layers = [nn.Conv2d(obs_shape[0], 32, 3, stride=2), nn.ReLU()]
+        for _ in range(3):
+            layers += [nn.Conv2d(32, 32, 3, stride=1), nn.ReLU()]
+        self.convnet = nn.Sequential(*layers)
+        self.apply(utils.weight_init)
+
+    def forward(self, obs):
+        """obs: uint8 or float [B,C,84,84] on the GPU -> [B, 39200] (inference path, drqv2.py:63-67)."""
+        if obs.dtype == torch.uint8:
+            x = ops.u8_normalize(obs.contiguous())
+        else:
+            x = (obs.float() / 255.0 - 0.5).contiguous()
+        for li, i in enumerate((0, 2, 4, 6)):
+            conv = self.convnet[i]
+            x = ops.conv3x3_fwd(x, conv.weight.data, conv.bias.data, 2 if li == 0 else 1, relu=True)
+        return x.view(x.shape[0], -1)
+
+
+def _trunk(seq, obs):
+    z = ops.linear_fwd(obs.contiguous(), seq[0].weight.data, seq[0].bias.data)
+    return ops.ln_tanh_fwd(z, seq[1].weight.data, seq[1].bias.data, save=False)[0]
+
+
+def _mlp3(seq, x):
+    x = ops.linear_fwd(x, seq[0].weight.data, seq[0].bias.data, relu=True)
+    x = ops.linear_fwd(x, seq[2].weight.data, seq[2].bias.data, relu=True)
+    return ops.linear_fwd(x, seq[4].weight.data, seq[4].bias.data)
+
+
+class Actor(nn.Module):
+    def __init__(self, repr_dim, action_shape, feature_dim, hidden_dim):
+        super().__init__()
+        self.trunk = nn.Sequential(nn.Linear(repr_dim, feature_dim), nn.LayerNorm(feature_dim), nn.Tanh())
+        self.policy = nn.Sequential(nn.Linear(feature_dim, hidden_dim), nn.ReLU(inplace=True),
+                                    nn.Linear(hidden_dim, hidden_dim), nn.ReLU(inplace=True),
+                                    nn.Linear(hidden_dim, action_shape[0]))
+        self.apply(utils.weight_init)
+
+    def forward(self, obs, std):
+        mu = ops.tanh(_mlp3(self.policy, _trunk(self.trunk, obs)))
+        return utils.TruncatedNormal(mu, torch.ones_like(mu) * std)
+
+
+class Critic(nn.Module):
+    def __init__(self, repr_dim, action_shape, feature_dim, hidden_dim):
+        super().__init__()
+        self.trunk = nn.Sequential(nn.Linear(repr_dim, feature_dim), nn.LayerNorm(feature_dim), nn.Tanh())
+
+        def q_head():
+            return nn.Sequential(nn.Linear(feature_dim + action_shape[0], hidden_dim), nn.ReLU(inplace=True),
+                                 nn.Linear(hidden_dim, hidden_dim), nn.ReLU(inplace=True), nn.Linear(hidden_dim, 1))
+
+        self.Q1 = q_head()
+        self.Q2 = q_head()
+        self.apply(utils.weight_init)
+
+    def forward(self, obs, action):
+        h_action = torch.cat([_trunk(self.trunk, obs), action], dim=-1).contiguous()
+        return _mlp3(self.Q1, h_action), _mlp3(self.Q2, h_action)
+
+
+class DrQV2Agent:
+    def __init__(self, obs_shape, action_shape, device, lr, feature_dim, hidden_dim, critic_target_tau,
+                 num_expl_steps, update_every_steps, stddev_schedule, stddev_clip, use_tb):
+        self._init_kwargs = dict(obs_shape=tuple(obs_shape), action_shape=tuple(action_shape), device=device, lr=lr,
+                                 feature_dim=feature_dim, hidden_dim=hidden_dim,
+                                 critic_target_tau=critic_target_tau, num_expl_steps=num_expl_steps,
+                                 update_every_steps=update_every_steps, stddev_schedule=stddev_schedule,
+                                 stddev_clip=stddev_clip, use_tb=use_tb)
+        self.device = device
+        self.critic_target_tau = critic_target_tau
+        self.update_every_steps = update_every_steps
+        self.use_tb = use_tb
+        self.num_expl_steps = num_expl_steps
+        self.stddev_schedule = stddev_schedule
+        self.stddev_clip = stddev_clip
+
+        # models: same construction order as drqv2.py:137-145 (RNG stream parity)
+        self.encoder = Encoder(obs_shape).to(device)
+        self.actor = Actor(self.encoder.repr_dim, action_shape, feature_dim, hidden_dim).to(device)
+        self.critic = Critic(self.encoder.repr_dim, action_shape, feature_dim, hidden_dim).to(device)
+        self.critic_target = Critic(self.encoder.repr_dim, action_shape, feature_dim, hidden_dim).to(device)
+        self.critic_target.load_state_dict(self.critic.state_dict())
+
+        # arenas + fused optimisers (replace the three torch.optim.Adam of drqv2.py:148-150)
+        self._engine = StepEngine(self.encoder, self.actor, self.critic, self.critic_target, obs_shape,
+                                  action_shape[0], feature_dim, hidden_dim, lr, device)
+        self.encoder_opt = self._engine.encoder_opt
+        self.actor_opt = self._engine.actor_opt
+        self.critic_opt = self._engine.critic_opt
+
+        self.aug = RandomShiftsAug(pad=4)
+        self._draw_hook = None     # tests inject the four random draws here
+
+        self.train()
+        self.critic_target.train()
+
+    def train(self, training=True):
+        self.training = training
+        self.encoder.train(training)
+        self.actor.train(training)
+        self.critic.train(training)
+
+    # ---- drqv2.py:164-175 ----------------------------------------------------------------------
+    def act(self, obs, step, eval_mode):
+        obs = torch.as_tensor(obs, device=self.device)
+        mu = self._engine.act_forward(obs.unsqueeze(0).contiguous())
+        stddev = utils.schedule(self.stddev_schedule, step)
+        dist = utils.TruncatedNormal(mu, torch.ones_like(mu) * stddev)
+        if eval_mode:
+            action = dist.mean
+        else:
+            action = dist.sample(clip=None)
+            if step < self.num_expl_steps:
+                action.uniform_(-1.0, 1.0)
+        return action.cpu().numpy()[0]
+
+    # ---- data parallel (new: one process per GPU, RCCL all-reduce of the flat gradient arenas) ---
+    def enable_data_parallel(self, process_group=None, batch_is_global=True):
+        """batch_is_global: every rank's replay_iter yields the same global batch and this rank trains
+        on its contiguous slice; otherwise the iterator already yields this rank's shard."""
+        self._engine.enable_data_parallel(process_group)
+        self._batch_is_global = batch_is_global
+
+    def _draws(self, n_global, A):
+        if self._draw_hook is not None:
+            return self._draw_hook(n_global, A)
+        dev = self.device
+        sh_o = self.aug.draw(n_global, dev)                                        # RNG draw 1 (drqv2.py:241)
+        sh_n = self.aug.draw(n_global, dev)                                        # RNG draw 2 (:242)
+        n_c = _standard_normal((n_global, A), dtype=torch.float32, device=dev)     # draw 3 (:183)
+        n_a = _standard_normal((n_global, A), dtype=torch.float32, device=dev)     # draw 4 (:211)
+        return sh_o, sh_n, n_c, n_a
+
+    # ---- drqv2.py:230-262 ----------------------------------------------------------------------
+    def update(self, replay_iter, step):
+        metrics = dict()
+        if step % self.update_every_steps != 0:
+            return metrics
+
+        batch = next(replay_iter)
+        obs, action, reward, discount, next_obs = utils.to_torch(batch, self.device)
+        eng = self._engine
+        A = eng.A
+        world, rank = eng.world, eng.rank
+        if world > 1 and getattr(self, "_batch_is_global", True):
+            n_global = obs.shape[0]
+            assert n_global % world == 0, "global batch must divide evenly over the ranks"
+            per = n_global // world
+            lo, hi = rank * per, (rank + 1) * per
+            obs_l, action_l, reward_l, discount_l, next_l = (t[lo:hi] for t in (obs, action, reward, discount,
+                                                                                 next_obs))
+        else:
+            per = obs.shape[0]
+            n_global = per * world
+            lo, hi = rank * per, (rank + 1) * per
+            obs_l, action_l, reward_l, discount_l, next_l = obs, action, reward, discount, next_obs
+        # every rank draws for the GLOBAL batch and keeps its slice: same numbers as the 1-GPU run
+        sh_o, sh_n, n_c, n_a = (t.reshape(n_global, -1)[lo:hi].contiguous() for t in self._draws(n_global, A))
+
+        stddev = utils.schedule(self.stddev_schedule, step)
+        f32 = lambda t: t.to(torch.float32).contiguous()
+        sums = eng.update(obs_l.contiguous(), f32(action_l), f32(reward_l).view(-1), f32(discount_l).view(-1),
+                          next_l.contiguous(), f32(sh_o), f32(sh_n), f32(n_c), f32(n_a), stddev, self.stddev_clip,
+                          self.critic_target_tau, B_global=n_global)
+
+        if self.use_tb:
+            s = sums.tolist()            # the single device->host sync of the update
+            inv = 1.0 / n_global
+            metrics["batch_reward"] = s[0] * inv
+            metrics["critic_target_q"] = s[1] * inv
+            metrics["critic_q1"] = s[2] * inv
+            metrics["critic_q2"] = s[3] * inv
+            metrics["critic_loss"] = s[4] * inv
+            metrics["actor_loss"] = s[5] * inv
+            metrics["actor_logprob"] = s[6] * inv
+            metrics["actor_ent"] = A * (0.5 + 0.5 * math.log(2 * math.pi) + math.log(stddev))
+        return metrics
+
+    # ---- snapshots: train.py:192-204 pickles the whole agent --------------------------------
+    def __getstate__(self):
+        cpu = lambda sd: {k: v.detach().cpu().clone() for k, v in sd.items()}
+        return {"init": self._init_kwargs, "training": self.training,
+                "encoder": cpu(self.encoder.state_dict()), "actor": cpu(self.actor.state_dict()),
+                "critic": cpu(self.critic.state_dict()), "critic_target": cpu(self.critic_target.state_dict()),
+                "opt": {n: getattr(self, n).export_state() for n in ("encoder_opt", "actor_opt", "critic_opt")}}
+
+    def __setstate__(self, st):
+        kw = dict(st["init"])
+        if str(kw["device"]).startswith("cuda") and not torch.cuda.is_available():
+            kw["device"] = "cpu"
+        with torch.random.fork_rng(devices=[]):      # building the nets must not move the global RNG
+            self.__init__(**kw)
+        self.encoder.load_state_dict(st["encoder"])
+        self.actor.load_state_dict(st["actor"])
+        self.critic.load_state_dict(st["critic"])
+        self.critic_target.load_state_dict(st["critic_target"])
+        for n, s in st["opt"].items():
+            getattr(self, n).import_state(s)
+        self.train(st["training"])

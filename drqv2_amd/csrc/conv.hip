@@ -1,0 +1,381 @@
+// 3x3 "valid" convolution of the DrQ-v2 encoder on the f32 matrix cores of gfx950.
+//
+// Reference op: nn.Conv2d(Cin,32,3,stride) + ReLU, drqv2.py:55-59, and its autograd
+// backward (dgrad for conv2..4, wgrad for conv1..4).
+//
+// Forward / dgrad kernel (conv3x3_kernel): implicit GEMM  D[cout][pixel] += W[cout][k] * X[k][pixel]
+// with v_mfma_f32_32x32x2_f32 (exact f32 fma chain).  A = weights, held for the whole kernel in
+// registers (one VGPR per k-pair: CP*9 VGPRs, 144 for Cin=32); B = input, one dword per lane per
+// MFMA fetched with a bounds-checked buffer load straight from global memory/L2 (each element is
+// re-used by 32 output channels inside the MFMA and by the 9 taps through L1); a "pixel tile" is 32
+// consecutive output pixels of the flattened (sample,y,x) index, so tiles are always full.
+// k is ordered (channel pair c, tap t): lanes 0-31 take channel 2c, lanes 32-63 channel 2c+1.
+// The dgrad of a stride-1 3x3 valid conv is the same kernel run on the zero-padded (pad 2)
+// output gradient with W transposed and flipped (gather mode 1), epilogue = ReLU mask.
+//
+// Wgrad kernel (conv3x3_wgrad_kernel): D[cout][col] += dY[cout][pixel] * X[pixel][col], reduction over
+// all B*Hout*Wout pixels.  Each wave owns a contiguous run of output rows, stages the dY row and the
+// three input rows through a wave-private LDS tile (coalesced global loads, odd pitches so that the
+// channel-strided MFMA operand reads are bank-conflict free), keeps all 9 (taps) x 32x32 accumulators
+// in registers, and the partials are reduced deterministically (fixed order, no atomics).
+#include "common.h"
+
+namespace {
+
+struct ConvArgs {
+  const float* x;      // [NB][CIN][HIN][HIN]
+  const float* w;      // canonical [32][CINW][3][3]
+  const float* bias;   // [32] or null
+  const float* mask;   // [NB][32][HOUT][HOUT] or null : out *= (mask > 0)
+  float* y;
+  long y_bs, y_cs, y_rs, y_off;   // output strides (elements)
+  unsigned x_bytes;
+  int nb;
+  int relu;
+  int wmode;           // 0 forward gather, 1 dgrad gather (transposed + flipped)
+};
+
+template <int CIN, int HIN, int STRIDE>
+__global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
+  constexpr int CP = (CIN + 1) / 2;
+  constexpr int HOUT = (HIN - 3) / STRIDE + 1;
+  constexpr int P = HOUT * HOUT;
+  const int lane = threadIdx.x & 63;
+  const int col = lane & 31;   // MFMA: A row (cout) for the weights, B column (pixel) for the input
+  const int half = lane >> 5;  // k parity -> channel parity
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * 256) >> 6;
+
+  // ---- weights -> registers (A operand), once per wave
+  float wreg[CP * 9];
+#pragma unroll
+  for (int c = 0; c < CP; ++c) {
+    const int kc = 2 * c + half;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float v = 0.f;
+      if (kc < CIN) {
+        const int idx = (a.wmode == 0) ? (col * CIN + kc) * 9 + t : (kc * 32 + col) * 9 + (8 - t);
+        v = a.w[idx];
+      }
+      wreg[c * 9 + t] = v;
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const long total = (long)a.nb * P;
+  const long ntiles = (total + 31) >> 5;
+
+  // per-lane byte offset of a tile's pixel (clamped for the ragged last tile)
+  auto tile_voff = [&](long tile) {
+    long p = tile * 32 + col;
+    if (p >= total) p = total - 1;
+    const int b = (int)(p / P);
+    const int rem = (int)(p - (long)b * P);
+    const int oy = rem / HOUT;
+    const int ox = rem - oy * HOUT;
+    return (((b * CIN + half) * HIN + oy * STRIDE) * HIN + ox * STRIDE) * 4;
+  };
+  auto load_group = [&](float (&dst)[9], int voff, int c) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int soff = ((2 * c) * HIN * HIN + (t / 3) * HIN + (t % 3)) * 4;
+      dst[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
+    }
+  };
+
+  // software pipeline: the 9 taps of channel pair c+1 (or of the next tile's pair 0) are in
+  // flight while the 9 MFMAs of pair c issue (9 x 64 cycles of cover for an L2 round trip).
+  float cur[9], nxt[9];
+  long tile = wave;
+  int voff = 0;
+  if (tile < ntiles) {
+    voff = tile_voff(tile);
+    load_group(cur, voff, 0);
+  }
+  for (; tile < ntiles; tile += nwaves) {
+    const long ntile = tile + nwaves < ntiles ? tile + nwaves : tile;   // last: harmless re-load
+    const int nvoff = tile_voff(ntile);
+
+    // accumulator row (cout) of register r: (r&3) + 8*(r>>2) + 4*half; C-in = bias
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = a.bias ? a.bias[(r & 3) + 8 * (r >> 2) + 4 * half] : 0.f;
+
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+      if (c + 1 < CP) load_group(nxt, voff, c + 1);
+      else load_group(nxt, nvoff, 0);
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[c * 9 + t], cur[t], acc, 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) cur[t] = nxt[t];
+    }
+
+    const long p = tile * 32 + col;
+    if (p < total) {
+      const int b = (int)(p / P);
+      const int rem = (int)(p - (long)b * P);
+      const int oy = rem / HOUT;
+      const int ox = rem - oy * HOUT;
+      float* yo = a.y + a.y_off + (long)b * a.y_bs + (long)oy * a.y_rs + ox;
+      const float* mk = a.mask ? a.mask + ((long)b * 32) * P + rem : nullptr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = acc[r];
+        if (a.relu) v = v > 0.f ? v : 0.f;
+        if (mk) v = (mk[(long)co * P] > 0.f) ? v : 0.f;
+        yo[(long)co * a.y_cs] = v;
+      }
+    }
+    voff = nvoff;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+  const float* x;     // layer input  [NB][CIN][HIN][HIN]
+  const float* dy;    // grad of the pre-activation, [NB][32][dy rows][dy cols] addressed with strides
+  long dy_bs, dy_cs, dy_rs, dy_off;
+  float* part;        // [nblocks][NT*1024 + 32]
+  int nb;
+};
+
+template <int CIN, int HIN, int STRIDE>
+struct WgradGeom {
+  static constexpr int HOUT = (HIN - 3) / STRIDE + 1;
+  static constexpr int KS = (HOUT + 1) / 2;                 // k-steps (pixel pairs) per output row
+  static constexpr int XW = (2 * KS - 1) * STRIDE + 3;      // columns touched (>= HIN)
+  static constexpr int XP = (XW | 1);                       // odd LDS pitch of an input row
+  static constexpr int DP = ((2 * KS) | 1);                 // odd LDS pitch of a dY row
+  static constexpr bool SMALL = (CIN * 3 <= 32);            // conv1: columns = (ci,kx), tiles = ky
+  static constexpr int NT = SMALL ? 3 : 9;
+  static constexpr int XS = 3 * CIN * XP;                   // floats of X per wave
+  static constexpr int WAVE_LDS = XS + 32 * DP;             // floats per wave
+  static constexpr int PART = NT * 1024 + 64;               // floats per partial record
+};
+
+template <int CIN, int HIN, int STRIDE>
+__global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(WgradArgs a) {
+  using G = WgradGeom<CIN, HIN, STRIDE>;
+  constexpr int HOUT = G::HOUT, KS = G::KS, XP = G::XP, DP = G::DP, NT = G::NT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  const int col = lane & 31;
+  const int half = lane >> 5;
+  float* xs = smem + wid * G::WAVE_LDS;
+  float* ds = xs + G::XS;
+
+  // zero the wave-private tile once: pad columns must hold finite values (they meet dY == 0)
+  for (int i = lane; i < G::WAVE_LDS; i += 64) xs[i] = 0.f;
+
+  // this lane's operand base addresses (floats)
+  int bbase;   // B operand: X[pixel][column]
+  if (G::SMALL) {
+    const int ci = col < CIN * 3 ? col / 3 : 0;
+    const int kx = col < CIN * 3 ? col % 3 : 0;
+    bbase = ci * XP + kx + half * STRIDE;
+  } else {
+    bbase = (col < CIN ? col : 0) * XP + half * STRIDE;
+  }
+  const int abase = col * DP + half;   // A operand: dY[cout][pixel]
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;
+
+  const long units = (long)a.nb * HOUT;       // (sample, output row)
+  const long nw = (long)gridDim.x * 4;
+  const long gw = (long)blockIdx.x * 4 + wid;
+  const long u0 = units * gw / nw, u1 = units * (gw + 1) / nw;
+
+  for (long u = u0; u < u1; ++u) {
+    const int b = (int)(u / HOUT);
+    const int oy = (int)(u - (long)b * HOUT);
+    // ---- stage: 3 input rows x CIN channels, one dY row x 32 channels (coalesced along x)
+    const float* xg = a.x + ((long)b * CIN * HIN + (long)oy * STRIDE) * HIN;
+    for (int i = lane; i < 3 * CIN * HIN; i += 64) {
+      const int ky = i / (CIN * HIN);
+      const int r2 = i - ky * (CIN * HIN);
+      const int ci = r2 / HIN;
+      const int xx = r2 - ci * HIN;
+      xs[(ky * CIN + ci) * XP + xx] = xg[((long)ci * HIN + ky) * HIN + xx];
+    }
+    const float* dg = a.dy + a.dy_off + (long)b * a.dy_bs + (long)oy * a.dy_rs;
+    for (int i = lane; i < 32 * HOUT; i += 64) {
+      const int co = i / HOUT;
+      const int xx = i - co * HOUT;
+      ds[co * DP + xx] = dg[(long)co * a.dy_cs + xx];
+    }
+    // (single wave: LDS operations of one wave complete in order, no barrier needed)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float av = ds[abase + 2 * s];
+      bsum += av;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int off = G::SMALL ? (t * CIN * XP + 2 * s * STRIDE)
+                                 : ((t / 3) * CIN * XP + (t % 3) + 2 * s * STRIDE);
+        const float bv = xs[bbase + off];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- reduce the 4 waves of the block through LDS, one partial record per block
+  __syncthreads();
+  float* red = smem;   // [4][NT*1024 + 64]  (fits: checked on the host)
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wid * G::PART + t * 1024 + r * 64 + lane] = acc[t][r];
+  red[wid * G::PART + NT * 1024 + lane] = bsum;
+  __syncthreads();
+  float* out = a.part + (long)blockIdx.x * G::PART;
+  for (int i = threadIdx.x; i < G::PART; i += 256)
+    out[i] = (red[i] + red[G::PART + i]) + (red[2 * G::PART + i] + red[3 * G::PART + i]);
+}
+
+// sums the per-block partial records in a fixed order and scatters to the canonical layouts
+template <int CIN, bool SMALL>
+__global__ void conv3x3_wgrad_reduce_kernel(const float* part, int nblocks, float* dw, float* db) {
+  constexpr int NT = SMALL ? 3 : 9;
+  constexpr int PART = NT * 1024 + 64;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= PART) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = 0;
+  for (; k + 3 < nblocks; k += 4) {
+    s0 += part[(long)(k + 0) * PART + i];
+    s1 += part[(long)(k + 1) * PART + i];
+    s2 += part[(long)(k + 2) * PART + i];
+    s3 += part[(long)(k + 3) * PART + i];
+  }
+  for (; k < nblocks; ++k) s0 += part[(long)k * PART + i];
+  const float s = (s0 + s1) + (s2 + s3);
+  if (i < NT * 1024) {
+    const int t = i >> 10, r = (i >> 6) & 15, lane = i & 63;
+    const int col = lane & 31, half = lane >> 5;
+    const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (SMALL) {
+      if (col < CIN * 3) dw[(co * CIN + col / 3) * 9 + t * 3 + col % 3] = s;
+    } else {
+      if (col < CIN) dw[(co * CIN + col) * 9 + t] = s;
+    }
+  } else {
+    // bias partials: lane (cout, half); the two halves hold even / odd pixels
+    const int lane = i - NT * 1024;
+    if (lane < 32) {
+      float o = 0.f;
+      for (int k2 = 0; k2 < nblocks; ++k2) o += part[(long)k2 * PART + NT * 1024 + lane + 32];
+      db[lane] = s + o;
+    }
+  }
+}
+
+template <int CIN, int HIN, int STRIDE>
+int launch_conv(const ConvArgs& a, hipStream_t st) {
+  constexpr int HOUT = (HIN - 3) / STRIDE + 1;
+  const long ntiles = ((long)a.nb * HOUT * HOUT + 31) / 32;
+  long blocks = (ntiles + 3) / 4;
+  const long cap = 2L * drq_num_cus();
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL((conv3x3_kernel<CIN, HIN, STRIDE>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
+template <int CIN, int HIN, int STRIDE>
+int launch_wgrad(const WgradArgs& a0, float* dw, float* db, float* ws, size_t ws_bytes, hipStream_t st) {
+  using G = WgradGeom<CIN, HIN, STRIDE>;
+  static_assert(4 * G::WAVE_LDS * 4 <= 160 * 1024, "LDS tile too large");
+  static_assert(4 * G::PART * 4 <= 160 * 1024, "reduction tile too large");
+  constexpr int lds_floats = (4 * G::WAVE_LDS > 4 * G::PART) ? 4 * G::WAVE_LDS : 4 * G::PART;
+  const long units = (long)a0.nb * G::HOUT;
+  long blocks = drq_num_cus();
+  if (blocks * 4 > units) blocks = (units + 3) / 4;
+  if (blocks < 1) blocks = 1;
+  if ((size_t)blocks * G::PART * sizeof(float) > ws_bytes) return DRQ_EWS;
+  WgradArgs a = a0;
+  a.part = ws;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel<CIN, HIN, STRIDE>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_floats * 4);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3x3_wgrad_kernel<CIN, HIN, STRIDE>), dim3((unsigned)blocks), dim3(256),
+                     lds_floats * 4, st, a);
+  DRQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL((conv3x3_wgrad_reduce_kernel<CIN, G::SMALL>), dim3((G::PART + 255) / 256), dim3(256), 0, st,
+                     (const float*)ws, (int)blocks, dw, db);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C ABI (declared in include/drqv2_hip.h)
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+// y = relu?(conv3x3(x, w) + bias); x [nb][cin][hin][hin], y written with the given strides.
+int drq_conv3x3_fwd(const float* x, const float* w, const float* bias, float* y, int nb, int cin, int hin,
+                    int stride, int relu, long y_bs, long y_cs, long y_rs, long y_off, hipStream_t st) {
+  if (!x || !w || !y || nb <= 0) return DRQ_EARG;
+  const size_t xb = (size_t)nb * cin * hin * hin * 4;
+  if (xb >= (1ull << 32)) return DRQ_EARG;
+  ConvArgs a{x, w, bias, nullptr, y, y_bs, y_cs, y_rs, y_off, (unsigned)xb, nb, relu, 0};
+  if (cin == 9 && hin == 84 && stride == 2) return launch_conv<9, 84, 2>(a, st);
+  if (cin == 32 && stride == 1) {
+    if (hin == 41) return launch_conv<32, 41, 1>(a, st);
+    if (hin == 39) return launch_conv<32, 39, 1>(a, st);
+    if (hin == 37) return launch_conv<32, 37, 1>(a, st);
+  }
+  return DRQ_EARG;
+}
+
+// dx = conv_transpose(dy, w) * (mask > 0): dy_pad is the pre-activation gradient stored zero-padded by 2
+// ([nb][32][hout+4][hout+4]); the result has the layer-input size hin = hout+2 and is written with strides.
+int drq_conv3x3_dgrad(const float* dy_pad, const float* w, const float* mask, float* dx, int nb, int hout,
+                      long dx_bs, long dx_cs, long dx_rs, long dx_off, hipStream_t st) {
+  if (!dy_pad || !w || !dx || nb <= 0) return DRQ_EARG;
+  const int hp = hout + 4;
+  const size_t xb = (size_t)nb * 32 * hp * hp * 4;
+  if (xb >= (1ull << 32)) return DRQ_EARG;
+  ConvArgs a{dy_pad, w, nullptr, mask, dx, dx_bs, dx_cs, dx_rs, dx_off, (unsigned)xb, nb, 0, 1};
+  if (hp == 39) return launch_conv<32, 39, 1>(a, st);
+  if (hp == 41) return launch_conv<32, 41, 1>(a, st);
+  if (hp == 43) return launch_conv<32, 43, 1>(a, st);
+  return DRQ_EARG;
+}
+
+// dw[32][cin][3][3], db[32] from the layer input x and the pre-activation gradient dy (strided view).
+int drq_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, int nb, int cin, int hin,
+                      int stride, long dy_bs, long dy_cs, long dy_rs, long dy_off, float* ws, size_t ws_bytes,
+                      hipStream_t st) {
+  if (!x || !dy || !dw || !db || !ws || nb <= 0) return DRQ_EARG;
+  WgradArgs a{x, dy, dy_bs, dy_cs, dy_rs, dy_off, nullptr, nb};
+  if (cin == 9 && hin == 84 && stride == 2) return launch_wgrad<9, 84, 2>(a, dw, db, ws, ws_bytes, st);
+  if (cin == 32 && stride == 1) {
+    if (hin == 41) return launch_wgrad<32, 41, 1>(a, dw, db, ws, ws_bytes, st);
+    if (hin == 39) return launch_wgrad<32, 39, 1>(a, dw, db, ws, ws_bytes, st);
+    if (hin == 37) return launch_wgrad<32, 37, 1>(a, dw, db, ws, ws_bytes, st);
+  }
+  return DRQ_EARG;
+}
+
+size_t drq_conv3x3_wgrad_ws_bytes(void) { return (size_t)1024 * (9 * 1024 + 64) * sizeof(float); }
+
+}  // extern "C"

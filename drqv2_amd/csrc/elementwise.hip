@@ -1,0 +1,529 @@
+// HBM-bound and tiny kernels of the DrQ-v2 update step:
+//   RandomShiftsAug (drqv2.py:19-45) fused with the encoder's /255-0.5 (drqv2.py:64),
+//   LayerNorm+Tanh forward/backward (drqv2.py:74-75), TruncatedNormal sample (utils.py:112-126),
+//   TD target + twin MSE (drqv2.py:185-189), actor loss (drqv2.py:212-216, 225-226),
+//   bias-gradient column sums, Adam (torch/optim/adam.py) with optional fused Polyak (utils.py:42-45).
+// All reductions are fixed-order (no float atomics): results are run-to-run bit-stable.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// RandomShiftsAug: replicate-pad by `pad`, bilinear grid_sample (zeros, align_corners=False) at
+// base[j] + shift*2/S.  One thread per output pixel, looping over channels (coordinates and the
+// four tap weights are per (sample,y,x)).  Arithmetic follows ATen's GridSampler scalar formulas.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void aug_kernel(const T* __restrict__ obs, const float* __restrict__ shift,
+                           const float* __restrict__ base, float* __restrict__ out, int n, int c, int h,
+                           int pad, int fuse_norm) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int hw = h * h;
+  if (idx >= (long)n * hw) return;
+  const int b = (int)(idx / hw);
+  const int r = (int)(idx - (long)b * hw);
+  const int i = r / h, j = r - i * h;
+  const int S = h + 2 * pad;
+  const float sc = (float)(2.0 / (double)S);
+  const float gx = base[j] + shift[2 * b + 0] * sc;
+  const float gy = base[i] + shift[2 * b + 1] * sc;
+  const float ix = ((gx + 1.f) * (float)S - 1.f) / 2.f;
+  const float iy = ((gy + 1.f) * (float)S - 1.f) / 2.f;
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int x0 = (int)fx, y0 = (int)fy;
+  const float wx1 = ix - fx, wx0 = (fx + 1.f) - ix;
+  const float wy1 = iy - fy, wy0 = (fy + 1.f) - iy;
+  const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;   // nw, ne, sw, se
+  const bool okx0 = x0 >= 0 && x0 < S, okx1 = x0 + 1 >= 0 && x0 + 1 < S;
+  const bool oky0 = y0 >= 0 && y0 < S, oky1 = y0 + 1 >= 0 && y0 + 1 < S;
+  auto cl = [&](int v) { v -= pad; return v < 0 ? 0 : (v > h - 1 ? h - 1 : v); };
+  const int sx0 = cl(x0), sx1 = cl(x0 + 1), sy0 = cl(y0), sy1 = cl(y0 + 1);
+  const T* src = obs + (long)b * c * hw;
+  float* dst = out + (long)b * c * hw + r;
+  for (int ch = 0; ch < c; ++ch) {
+    const T* s = src + (long)ch * hw;
+    float v = 0.f;
+    if (okx0 && oky0) v = __fmaf_rn((float)s[sy0 * h + sx0], w00, v);
+    if (okx1 && oky0) v = __fmaf_rn((float)s[sy0 * h + sx1], w01, v);
+    if (okx0 && oky1) v = __fmaf_rn((float)s[sy1 * h + sx0], w10, v);
+    if (okx1 && oky1) v = __fmaf_rn((float)s[sy1 * h + sx1], w11, v);
+    if (fuse_norm) v = v / 255.0f - 0.5f;
+    dst[(long)ch * hw] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm + tanh.  One wave per row, F <= 256.
+// ------------------------------------------------------------------------------------------------
+struct LnArgs {
+  const float* z[4];      // [rows][ldz] pre-norm (bias already added)
+  const float* gamma[4];
+  const float* beta[4];
+  float* out[4];          // [rows][ldo] tanh(LN(z))
+  float* xhat[4];         // [rows][F] (may be null)
+  float* rstd[4];         // [rows]   (may be null)
+  int ldz[4], ldo[4];
+  int rows, F;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ void ln_tanh_fwd_kernel(LnArgs a) {
+  const int g = blockIdx.y;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= a.rows) return;
+  const float* z = a.z[g] + (long)row * a.ldz[g];
+  float v[4];
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int f = lane + 64 * q;
+    v[q] = f < a.F ? z[f] : 0.f;
+    s += v[q];
+  }
+  const float mean = wave_sum(s) / (float)a.F;
+  float ss = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int f = lane + 64 * q;
+    const float d = f < a.F ? v[q] - mean : 0.f;
+    ss += d * d;
+  }
+  const float var = wave_sum(ss) / (float)a.F;
+  const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int f = lane + 64 * q;
+    if (f < a.F) {
+      const float xh = (v[q] - mean) * rstd;
+      const float y = xh * a.gamma[g][f] + a.beta[g][f];
+      a.out[g][(long)row * a.ldo[g] + f] = tanhf(y);
+      if (a.xhat[g]) a.xhat[g][(long)row * a.F + f] = xh;
+    }
+  }
+  if (lane == 0 && a.rstd[g]) a.rstd[g][row] = rstd;
+}
+
+struct LnBwdArgs {
+  const float* dh0;     // [rows][ld0] gradient w.r.t. tanh output (source 0)
+  const float* dh1;     // optional second source, summed
+  const float* h;       // [rows][ldh] saved tanh output
+  const float* xhat;    // [rows][F]
+  const float* rstd;    // [rows]
+  const float* gamma;
+  float* dz;            // [rows][F]
+  float* dln;           // [rows][F] scratch: gradient w.r.t. the LN output (for dgamma/dbeta)
+  int ld0, ld1, ldh;
+  int rows, F;
+};
+
+__global__ void ln_tanh_bwd_kernel(LnBwdArgs a) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= a.rows) return;
+  float dxh[4], xh[4];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int f = lane + 64 * q;
+    dxh[q] = 0.f;
+    xh[q] = 0.f;
+    if (f < a.F) {
+      float d = a.dh0[(long)row * a.ld0 + f];
+      if (a.dh1) d += a.dh1[(long)row * a.ld1 + f];
+      const float hv = a.h[(long)row * a.ldh + f];
+      const float dl = d * (1.f - hv * hv);
+      a.dln[(long)row * a.F + f] = dl;
+      xh[q] = a.xhat[(long)row * a.F + f];
+      dxh[q] = dl * a.gamma[f];
+      s1 += dxh[q];
+      s2 += dxh[q] * xh[q];
+    }
+  }
+  const float m1 = wave_sum(s1) / (float)a.F;
+  const float m2 = wave_sum(s2) / (float)a.F;
+  const float rs = a.rstd[row];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int f = lane + 64 * q;
+    if (f < a.F) a.dz[(long)row * a.F + f] = rs * (dxh[q] - m1 - xh[q] * m2);
+  }
+}
+
+// dgamma[f] = sum_rows dln*xhat, dbeta[f] = sum_rows dln.  One block (256 threads) per column.
+__global__ void ln_param_grad_kernel(const float* dln, const float* xhat, float* dgamma, float* dbeta, int rows,
+                                     int F) {
+  __shared__ float sg[256], sb[256];
+  const int f = blockIdx.x;
+  float g = 0.f, b = 0.f;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    const float d = dln[(long)r * F + f];
+    g += d * xhat[(long)r * F + f];
+    b += d;
+  }
+  sg[threadIdx.x] = g;
+  sb[threadIdx.x] = b;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      sg[threadIdx.x] += sg[threadIdx.x + o];
+      sb[threadIdx.x] += sb[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    dgamma[f] = sg[0];
+    dbeta[f] = sb[0];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// column sums (bias gradients): out[batch][n] = sum_m dy[batch][m][n].  Block = 64 columns x 4 row groups.
+// ------------------------------------------------------------------------------------------------
+__global__ void colsum_kernel(const float* dy, long ld, long dy_bs, float* out, long out_bs, int M, int N) {
+  __shared__ float s[4][64];
+  const int batch = blockIdx.y;
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rg = threadIdx.x >> 6;
+  const float* p = dy + batch * dy_bs;
+  float acc = 0.f;
+  if (n < N)
+    for (int m = rg; m < M; m += 4) acc += p[(long)m * ld + n];
+  s[rg][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rg == 0 && n < N) out[batch * out_bs + n] = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// policy head output: mu = tanh(pre); a = clampST(mu + clamp(noise*std, +-clip))   (utils.py:117-126)
+// ------------------------------------------------------------------------------------------------
+__global__ void sample_action_kernel(const float* pre, const float* noise, float std, float clip, int use_clip,
+                                     float* mu_out, float* a_out, long lda_out, int B, int A) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * A) return;
+  const int b = i / A, j = i - b * A;
+  const float mu = tanhf(pre[i]);
+  float eps = noise[i] * std;
+  if (use_clip) eps = fminf(fmaxf(eps, -clip), clip);
+  const float x = mu + eps;
+  const float lo = (float)(-1.0 + 1e-6), hi = (float)(1.0 - 1e-6);
+  const float a = fminf(fmaxf(x, lo), hi);
+  if (mu_out) mu_out[i] = mu;
+  a_out[(long)b * lda_out + j] = a;
+}
+
+__global__ void copy_cols_kernel(const float* src, int ld_src, float* dst, long ld_dst, int B, int A) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * A) return;
+  const int b = i / A, j = i - b * A;
+  dst[(long)b * ld_dst + j] = src[(long)b * ld_src + j];
+}
+
+// block-wide fixed-order sum of up to 4 values (256 threads)
+__device__ __forceinline__ void block_sum4(float (&v)[4], float (*sm)[256]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) sm[q][threadIdx.x] = v[q];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sm[q][threadIdx.x] += sm[q][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = sm[q][0];
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// TD target + twin MSE (drqv2.py:185-189).  Single block.  invB = 1/global batch.
+// sums[0..4] = sum reward, sum target_q, sum q1, sum q2, sum (q1-y)^2+(q2-y)^2  (un-normalised: the
+// data-parallel path adds them across ranks before dividing).
+// ------------------------------------------------------------------------------------------------
+__global__ void td_loss_kernel(const float* tq1, const float* tq2, const float* q1, const float* q2,
+                               const float* reward, const float* discount, float* dq1, float* dq2, float* sums,
+                               int B, float invB) {
+  __shared__ float sm[4][256];
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  float sr = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float y = reward[b] + discount[b] * fminf(tq1[b], tq2[b]);
+    const float e1 = q1[b] - y, e2 = q2[b] - y;
+    dq1[b] = 2.f * e1 * invB;
+    dq2[b] = 2.f * e2 * invB;
+    s[0] += y;
+    s[1] += q1[b];
+    s[2] += q2[b];
+    s[3] += e1 * e1 + e2 * e2;
+    sr += reward[b];
+  }
+  block_sum4(s, sm);
+  float r4[4] = {sr, 0.f, 0.f, 0.f};
+  block_sum4(r4, sm);
+  if (threadIdx.x == 0) {
+    sums[0] = r4[0];
+    sums[1] = s[0];
+    sums[2] = s[1];
+    sums[3] = s[2];
+    sums[4] = s[3];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// actor loss (drqv2.py:212-216): L = -mean(min(q1,q2)); gradient routed to the smaller head, ties split.
+// sums[5] = sum -min(q1,q2), sums[6] = sum_b sum_A log N(a|mu,std)
+// ------------------------------------------------------------------------------------------------
+__global__ void actor_loss_kernel(const float* q1, const float* q2, const float* a, long lda, const float* mu,
+                                  float std, float* dq1, float* dq2, float* sums, int B, int A, float invB) {
+  __shared__ float sm[4][256];
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  const float log_std = logf(std);
+  const float c = 0.91893853320467274178f;   // log(sqrt(2*pi))
+  const float var2 = 2.f * std * std;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float x = q1[b], y = q2[b];
+    s[0] += -fminf(x, y);
+    const float g = -invB;
+    dq1[b] = x < y ? g : (x == y ? 0.5f * g : 0.f);
+    dq2[b] = y < x ? g : (x == y ? 0.5f * g : 0.f);
+    float lp = 0.f;
+    for (int j = 0; j < A; ++j) {
+      const float d = a[(long)b * lda + j] - mu[b * A + j];
+      lp += -(d * d) / var2 - log_std - c;
+    }
+    s[1] += lp;
+  }
+  block_sum4(s, sm);
+  if (threadIdx.x == 0) {
+    sums[5] = s[0];
+    sums[6] = s[1];
+  }
+}
+
+// d(pre-tanh policy output) = (da1 + da2) * (1 - mu^2): straight-through clamp (utils.py:112-115),
+// da_k = action columns of head k's layer-1 input gradient.
+__global__ void actor_dmu_kernel(const float* dha1, const float* dha2, long ld, int col0, const float* mu,
+                                 float* dpre, int B, int A) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * A) return;
+  const int b = i / A, j = i - b * A;
+  const float da = dha1[(long)b * ld + col0 + j] + dha2[(long)b * ld + col0 + j];
+  const float m = mu[i];
+  dpre[i] = da * (1.f - m * m);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam defaults) over a flat arena, rounding sequence of torch's CPU kernels
+// (oracle/drq_oracle.py:adam_step), optional fused Polyak update of a target arena.
+// ------------------------------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n, float neg_step_size, float sqrt_bc2, float gscale,
+                            float* __restrict__ tgt, float tau, float one_minus_tau) {
+  const float w1 = (float)(1.0 - 0.9), b2 = 0.999f, w2 = (float)(1.0 - 0.999), eps = 1e-8f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float gi = g[i];
+    if (gscale != 1.0f) gi *= gscale;
+    const float mi = __fmaf_rn(w1, __fsub_rn(gi, m[i]), m[i]);
+    const float vi = __fmaf_rn(__fmul_rn(gi, w2), gi, __fmul_rn(v[i], b2));
+    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), sqrt_bc2), eps);
+    const float pi = __fmaf_rn(neg_step_size, __fdiv_rn(mi, denom), p[i]);
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = pi;
+    if (tgt) tgt[i] = __fadd_rn(__fmul_rn(tau, pi), __fmul_rn(one_minus_tau, tgt[i]));
+  }
+}
+
+__global__ void ema_kernel(const float* __restrict__ p, float* __restrict__ t, long n, float tau,
+                           float one_minus_tau) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    t[i] = __fadd_rn(__fmul_rn(tau, p[i]), __fmul_rn(one_minus_tau, t[i]));
+}
+
+__global__ void fill_kernel(float* p, long n, float v) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+__global__ void u8_normalize_kernel(const uint8_t* __restrict__ x, float* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = (float)x[i] / 255.0f - 0.5f;
+}
+
+__global__ void tanh_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = tanhf(x[i]);
+}
+
+inline unsigned grid_for(long n, int block = 256) {
+  long g = (n + block - 1) / block;
+  const long cap = 8L * drq_num_cus();
+  if (g > cap) g = cap;
+  return (unsigned)(g < 1 ? 1 : g);
+}
+
+}  // namespace
+
+extern "C" {
+
+int drq_aug_fwd(const uint8_t* obs, const float* shift_xy, const float* base_grid, float* out, int n, int c,
+                int hw, int pad, int fuse_norm, hipStream_t st) {
+  if (!obs || !shift_xy || !base_grid || !out || n <= 0 || c <= 0 || hw <= 0 || pad < 0) return DRQ_EARG;
+  const long total = (long)n * hw * hw;
+  hipLaunchKernelGGL(aug_kernel<uint8_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, obs, shift_xy,
+                     base_grid, out, n, c, hw, pad, fuse_norm);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
+// same op on a float frame (RandomShiftsAug.forward is handed obs.float(), drqv2.py:241)
+int drq_aug_fwd_f32(const float* x, const float* shift_xy, const float* base_grid, float* out, int n, int c, int hw,
+                    int pad, hipStream_t st) {
+  if (!x || !shift_xy || !base_grid || !out || n <= 0 || c <= 0 || hw <= 0 || pad < 0) return DRQ_EARG;
+  const long total = (long)n * hw * hw;
+  hipLaunchKernelGGL(aug_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, shift_xy, base_grid,
+                     out, n, c, hw, pad, 0);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
+int drq_ln_tanh_fwd(const float* z, int ldz, const float* gamma, const float* beta, float* out, int ldo,
+                    float* xhat, float* rstd, int rows, int F, hipStream_t st) {
+  if (!z || !gamma || !beta || !out || rows <= 0 || F <= 0 || F > 256) return DRQ_EARG;
+  LnArgs a{};
+  a.z[0] = z; a.gamma[0] = gamma; a.beta[0] = beta; a.out[0] = out; a.xhat[0] = xhat; a.rstd[0] = rstd;
+  a.ldz[0] = ldz; a.ldo[0] = ldo; a.rows = rows; a.F = F;
+  hipLaunchKernelGGL(ln_tanh_fwd_kernel, dim3((rows + 3) / 4, 1), dim3(256), 0, st, a);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
+// two LayerNorm+tanh problems of the same (rows, F) in one launch (actor trunk + critic trunk)
+int drq_ln_tanh_fwd2(const float* z0, const float* z1, int ldz, const float* gamma0, const float* beta0,
+                     const float* gamma1, const float* beta1, float* out0, int ldo0, float* out1, int ldo1,
+                     float* xhat0, float* rstd0, float* xhat1, float* rstd1, int rows, int F, hipStream_t st) {
+  if (!z0 || !z1 || !out0 || !out1 || rows <= 0 || F <= 0 || F > 256) return DRQ_EARG;
+  LnArgs a{};
+  a.z[0] = z0; a.gamma[0] = gamma0; a.beta[0] = beta0; a.out[0] = out0; a.xhat[0] = xhat0; a.rstd[0] = rstd0;
+  a.z[1] = z1; a.gamma[1] = gamma1; a.beta[1] = beta1; a.out[1] = out1; a.xhat[1] = xhat1; a.rstd[1] = rstd1;
+  a.ldz[0] = a.ldz[1] = ldz; a.ldo[0] = ldo0; a.ldo[1] = ldo1; a.rows = rows; a.F = F;
+  hipLaunchKernelGGL(ln_tanh_fwd_kernel, dim3((rows + 3) / 4, 2), dim3(256), 0, st, a);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
+int drq_ln_tanh_bwd(const float* dh0, int ld0, const float* dh1, int ld1, const float* h, int ldh,
+                    const float* xhat, const float* rstd, const float* gamma, float* dz, float* dln,
+                    float* dgamma, float* dbeta, int rows, int F, hipStream_t st) {
+  if (!dh0 || !h || !xhat || !rstd || !gamma || !dz || !dln || !dgamma || !dbeta || rows <= 0 || F <= 0 || F > 256)
+    return DRQ_EARG;
+  LnBwdArgs a{dh0, dh1, h, xhat, rstd, gamma, dz, dln, ld0, ld1, ldh, rows, F};
+  hipLaunchKernelGGL(ln_tanh_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, a);
+  DRQ_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ln_param_grad_kernel, dim3(F), dim3(256), 0, st, (const float*)dln, xhat, dgamma, dbeta, rows, F);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
+int drq_colsum(const float* dy, long ld, long dy_bs, float* out, long out_bs, int M, int N, int nbatch,
+               hipStream_t st) {
+  if (!dy || !out || M <= 0 || N <= 0 || nbatch <= 0) return DRQ_EARG;
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, nbatch), dim3(256), 0, st, dy, ld, dy_bs, out, out_bs, M, N);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
+int drq_trunc_normal_sample(const float* pre_tanh, const float* noise, float std, float clip, int use_clip,
+                            float* mu_out, float* a_out, long lda_out, int B, int A, hipStream_t st) {
+  if (!pre_tanh || !noise || !a_out || B <= 0 || A <= 0) return DRQ_EARG;
+  hipLaunchKernelGGL(sample_action_kernel, dim3((B * A + 255) / 256), dim3(256), 0, st, pre_tanh, noise, std, clip,
+                     use_clip, mu_out, a_out, lda_out, B, A);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
+int drq_copy_cols(const float* src, int ld_src, float* dst, long ld_dst, int B, int A, hipStream_t st) {
+  if (!src || !dst || B <= 0 || A <= 0) return DRQ_EARG;
+  hipLaunchKernelGGL(copy_cols_kernel, dim3((B * A + 255) / 256), dim3(256), 0, st, src, ld_src, dst, ld_dst, B, A);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
+int drq_td_mse(const float* tq1, const float* tq2, const float* q1, const float* q2, const float* reward,
+               const float* discount, float* dq1, float* dq2, float* sums, int B, float inv_global_B,
+               hipStream_t st) {
+  if (!tq1 || !tq2 || !q1 || !q2 || !reward || !discount || !dq1 || !dq2 || !sums || B <= 0) return DRQ_EARG;
+  hipLaunchKernelGGL(td_loss_kernel, dim3(1), dim3(256), 0, st, tq1, tq2, q1, q2, reward, discount, dq1, dq2, sums, B,
+                     inv_global_B);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
+int drq_actor_loss(const float* q1, const float* q2, const float* a, long lda, const float* mu, float std,
+                   float* dq1, float* dq2, float* sums, int B, int A, float inv_global_B, hipStream_t st) {
+  if (!q1 || !q2 || !a || !mu || !dq1 || !dq2 || !sums || B <= 0 || A <= 0) return DRQ_EARG;
+  hipLaunchKernelGGL(actor_loss_kernel, dim3(1), dim3(256), 0, st, q1, q2, a, lda, mu, std, dq1, dq2, sums, B, A,
+                     inv_global_B);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
+int drq_actor_dmu(const float* dha1, const float* dha2, long ld, int col0, const float* mu, float* dpre, int B,
+                  int A, hipStream_t st) {
+  if (!dha1 || !dha2 || !mu || !dpre || B <= 0 || A <= 0) return DRQ_EARG;
+  hipLaunchKernelGGL(actor_dmu_kernel, dim3((B * A + 255) / 256), dim3(256), 0, st, dha1, dha2, ld, col0, mu, dpre,
+                     B, A);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
+// step = 1-based Adam step count; bias corrections are formed in double on the host exactly as
+// torch/optim/adam.py does.  tgt != null fuses  tgt <- tau*p_new + (1-tau)*tgt.
+int drq_adam_flat(float* p, const float* g, float* m, float* v, long n, double lr, long step, float gscale,
+                  float* tgt, double tau, hipStream_t st) {
+  if (!p || !g || !m || !v || n <= 0 || step <= 0) return DRQ_EARG;
+  const double bc1 = 1.0 - pow(0.9, (double)step);
+  const double bc2 = 1.0 - pow(0.999, (double)step);
+  const float neg_step_size = (float)(-(lr / bc1));
+  const float sqrt_bc2 = (float)sqrt(bc2);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, g, m, v, n, neg_step_size, sqrt_bc2,
+                     gscale, tgt, (float)tau, (float)(1.0 - tau));
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
+int drq_ema_flat(const float* p, float* t, long n, double tau, hipStream_t st) {
+  if (!p || !t || n <= 0) return DRQ_EARG;
+  hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, t, n, (float)tau, (float)(1.0 - tau));
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
+// Encoder input conversion without augmentation (drqv2.py:64 on a uint8 frame, as act() does)
+int drq_u8_normalize(const uint8_t* x, float* y, long n, hipStream_t st) {
+  if (!x || !y || n <= 0) return DRQ_EARG;
+  hipLaunchKernelGGL(u8_normalize_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, y, n);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
+int drq_tanh(const float* x, float* y, long n, hipStream_t st) {
+  if (!x || !y || n <= 0) return DRQ_EARG;
+  hipLaunchKernelGGL(tanh_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, y, n);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
+int drq_fill(float* p, long n, float v, hipStream_t st) {
+  if (!p || n <= 0) return DRQ_EARG;
+  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, n, v);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
+}  // extern "C"

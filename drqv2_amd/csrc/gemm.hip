@@ -1,0 +1,272 @@
+// f32 GEMM for the fully connected layers of DrQ-v2 (trunk, policy, Q heads; drqv2.py:74-81,100-111)
+// on v_mfma_f32_16x16x4_f32 (exact f32 fma chain, k-ordered).
+//
+//   C[m][n] = epilogue( sum_k A(m,k) * B(k,n) )
+//
+// Operand addressing covers the three shapes autograd needs without materialising transposes:
+//   A_KC: A(m,k) = A[m*lda + k]   else   A(m,k) = A[k*lda + m]
+//   B_KC: B(k,n) = B[n*ldb + k]   else   B(k,n) = B[k*ldb + n]
+//   forward  y = x W^T : A_KC, B_KC      dgrad  dx = dy W : A_KC, !B_KC      wgrad  dW = dy^T x : !A_KC, !B_KC
+// Workgroup = 4 waves (2x2); wave tile = TMxTN MFMA tiles of 16x16; block tile (32*TM)x(32*TN), BK = 32.
+// Global -> registers (prefetched one k-tile ahead) -> LDS [row][k] with pitch 34 (bank = 2*row + k:
+// conflict-free MFMA operand reads) -> MFMA.  Split-K writes dense partials; a second kernel sums them
+// in a fixed order (deterministic) and applies the epilogue.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int PK = 34;
+
+struct Epilogue {
+  const float* bias;    // [N] (+ batch stride) or null
+  const float* aux;     // relu mask source [M][ldaux] or null : v = aux>0 ? v : 0
+  long bias_bs, aux_bs;
+  int ldaux;
+  int relu;
+  int scatter_hw;       // >0: C index = padded NCHW scatter (trunk dgrad -> conv4 grad layout, pad 2)
+};
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  long lda, ldb, ldc;
+  long a_bs, b_bs, c_bs;     // batch strides (elements)
+  int M, N, K;
+  int nbatch, splitk, kchunk;
+  float* part;               // split-K partials [nbatch*splitk][M][N]
+  Epilogue ep;
+};
+
+__device__ __forceinline__ void epilogue_store(const GemmArgs& g, int batch, int m, int n, float v) {
+  const Epilogue& e = g.ep;
+  if (e.bias) v += e.bias[batch * e.bias_bs + n];
+  if (e.relu) v = v > 0.f ? v : 0.f;
+  if (e.aux) v = (e.aux[batch * e.aux_bs + (long)m * e.ldaux + n] > 0.f) ? v : 0.f;
+  float* c = g.C + batch * g.c_bs;
+  if (e.scatter_hw > 0) {
+    const int hw = e.scatter_hw, hp = hw + 4;
+    const int ch = n / (hw * hw);
+    const int r = n - ch * hw * hw;
+    const int y = r / hw, x = r - y * hw;
+    c[(((long)m * 32 + ch) * hp + (y + 2)) * hp + (x + 2)] = v;
+  } else {
+    c[(long)m * g.ldc + n] = v;
+  }
+}
+
+// ---- global -> register tile loaders (BR rows of the block tile, BK columns of k)
+template <int BR, bool KC, bool V4>
+__device__ __forceinline__ void load_tile(const float* P, long ld, int row0, int rows, int k0, int kend,
+                                          float (&reg)[BR * BK / 256], int tid) {
+  if constexpr (KC && V4) {
+    // 8 threads x float4 along k per row, 32 rows per pass
+    const int r = tid >> 3, kq = (tid & 7) * 4;
+#pragma unroll
+    for (int p = 0; p < BR / 32; ++p) {
+      const int row = row0 + p * 32 + r;
+      const int k = k0 + kq;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row < rows && k < kend) v = *reinterpret_cast<const f32x4*>(P + (long)row * ld + k);
+      reg[p * 4 + 0] = v[0]; reg[p * 4 + 1] = v[1]; reg[p * 4 + 2] = v[2]; reg[p * 4 + 3] = v[3];
+    }
+  } else if constexpr (KC) {
+    // 32 lanes along k per row, 8 rows per pass
+    const int r = tid >> 5, kk = tid & 31;
+#pragma unroll
+    for (int p = 0; p < BR / 8; ++p) {
+      const int row = row0 + p * 8 + r;
+      const int k = k0 + kk;
+      reg[p] = (row < rows && k < kend) ? P[(long)row * ld + k] : 0.f;
+    }
+  } else {
+    // row index contiguous in memory: lanes along rows
+    const int r = tid % BR, kk0 = tid / BR;
+    constexpr int KSTEP = 256 / BR;
+#pragma unroll
+    for (int p = 0; p < BR * BK / 256; ++p) {
+      const int row = row0 + r;
+      const int k = k0 + kk0 + p * KSTEP;
+      reg[p] = (row < rows && k < kend) ? P[(long)k * ld + row] : 0.f;
+    }
+  }
+}
+
+template <int BR, bool KC, bool V4>
+__device__ __forceinline__ void store_tile(float* S, const float (&reg)[BR * BK / 256], int tid) {
+  if constexpr (KC && V4) {
+    const int r = tid >> 3, kq = (tid & 7) * 4;
+#pragma unroll
+    for (int p = 0; p < BR / 32; ++p) {
+      float* d = S + (p * 32 + r) * PK + kq;
+      d[0] = reg[p * 4 + 0]; d[1] = reg[p * 4 + 1]; d[2] = reg[p * 4 + 2]; d[3] = reg[p * 4 + 3];
+    }
+  } else if constexpr (KC) {
+    const int r = tid >> 5, kk = tid & 31;
+#pragma unroll
+    for (int p = 0; p < BR / 8; ++p) S[(p * 8 + r) * PK + kk] = reg[p];
+  } else {
+    const int r = tid % BR, kk0 = tid / BR;
+    constexpr int KSTEP = 256 / BR;
+#pragma unroll
+    for (int p = 0; p < BR * BK / 256; ++p) S[r * PK + kk0 + p * KSTEP] = reg[p];
+  }
+}
+
+template <int TM, int TN, bool A_KC, bool B_KC, bool V4>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  constexpr int BM = 32 * TM, BN = 32 * TN;
+  constexpr int RA = BM * BK / 256, RB = BN * BK / 256;   // prefetch registers per thread
+  __shared__ __attribute__((aligned(16))) float As[BM * PK];
+  __shared__ __attribute__((aligned(16))) float Bs[BN * PK];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int z = blockIdx.z;
+  const int batch = z / g.splitk, ks = z - batch * g.splitk;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kbeg = ks * g.kchunk;
+  const int kend = min(g.K, kbeg + g.kchunk);
+  const float* A = g.A + batch * g.a_bs;
+  const float* B = g.B + batch * g.b_bs;
+
+  float ra[RA], rb[RB];
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int arow = (wm * TM * 16 + (lane & 15)) * PK + (lane >> 4);
+  const int brow = (wn * TN * 16 + (lane & 15)) * PK + (lane >> 4);
+
+  if (kbeg < kend) {
+    load_tile<BM, A_KC, V4>(A, g.lda, m0, g.M, kbeg, kend, ra, tid);
+    load_tile<BN, B_KC, V4>(B, g.ldb, n0, g.N, kbeg, kend, rb, tid);
+  }
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    store_tile<BM, A_KC, V4>(As, ra, tid);
+    store_tile<BN, B_KC, V4>(Bs, rb, tid);
+    __syncthreads();
+    if (k0 + BK < kend) {
+      load_tile<BM, A_KC, V4>(A, g.lda, m0, g.M, k0 + BK, kend, ra, tid);
+      load_tile<BN, B_KC, V4>(B, g.ldb, n0, g.N, k0 + BK, kend, rb, tid);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[arow + i * 16 * PK + kk * 4];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bs[brow + j * 16 * PK + kk * 4];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- store: C/D layout col = lane&15, row = (lane>>4)*4 + reg
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * TM * 16 + i * 16 + (lane >> 4) * 4 + r;
+        const int n = n0 + wn * TN * 16 + j * 16 + (lane & 15);
+        if (m < g.M && n < g.N) {
+          if (g.splitk > 1)
+            g.part[((long)z * g.M + m) * g.N + n] = acc[i][j][r];
+          else
+            epilogue_store(g, batch, m, n, acc[i][j][r]);
+        }
+      }
+}
+
+__global__ void splitk_reduce_kernel(GemmArgs g) {
+  const long mn = (long)g.M * g.N;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int batch = blockIdx.y;
+  if (i >= mn) return;
+  const float* p = g.part + (long)batch * g.splitk * mn + i;
+  float s0 = 0.f, s1 = 0.f;
+  int k = 0;
+  for (; k + 1 < g.splitk; k += 2) {
+    s0 += p[(long)k * mn];
+    s1 += p[(long)(k + 1) * mn];
+  }
+  if (k < g.splitk) s0 += p[(long)k * mn];
+  const int m = (int)(i / g.N), n = (int)(i - (long)m * g.N);
+  epilogue_store(g, batch, m, n, s0 + s1);
+}
+
+template <int TM, int TN, bool A_KC, bool B_KC, bool V4>
+int launch(const GemmArgs& g, hipStream_t st) {
+  constexpr int BM = 32 * TM, BN = 32 * TN;
+  dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.nbatch * g.splitk);
+  hipLaunchKernelGGL((gemm_kernel<TM, TN, A_KC, B_KC, V4>), grid, dim3(256), 0, st, g);
+  DRQ_LAUNCH_CHECK();
+  if (g.splitk > 1) {
+    const long mn = (long)g.M * g.N;
+    dim3 rg((unsigned)((mn + 255) / 256), g.nbatch);
+    hipLaunchKernelGGL(splitk_reduce_kernel, rg, dim3(256), 0, st, g);
+    DRQ_LAUNCH_CHECK();
+  }
+  return DRQ_OK;
+}
+
+template <int TM, int TN>
+int dispatch(const GemmArgs& g, int a_kc, int b_kc, bool v4, hipStream_t st) {
+  if (a_kc && b_kc) return v4 ? launch<TM, TN, true, true, true>(g, st) : launch<TM, TN, true, true, false>(g, st);
+  if (a_kc && !b_kc) return v4 ? launch<TM, TN, true, false, true>(g, st) : launch<TM, TN, true, false, false>(g, st);
+  if (!a_kc && !b_kc) return launch<TM, TN, false, false, false>(g, st);
+  return DRQ_EARG;
+}
+
+}  // namespace
+
+extern "C" {
+
+// See include/drqv2_hip.h.  tile: 1 = 32x32 block tile, 2 = 64x64, 0 = choose.  splitk: 0 = choose.
+int drq_gemm_f32(const float* A, long lda, int a_kc, const float* B, long ldb, int b_kc, float* C, long ldc,
+                 int M, int N, int K, int nbatch, long a_bs, long b_bs, long c_bs, const float* bias, long bias_bs,
+                 int relu, const float* aux, int ldaux, long aux_bs, int scatter_hw, int tile, int splitk,
+                 float* ws, size_t ws_bytes, hipStream_t st) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || nbatch <= 0) return DRQ_EARG;
+  const int cus = drq_num_cus();
+  const long t_big = (long)((M + 63) / 64) * ((N + 63) / 64) * nbatch;
+  const long t_small = (long)((M + 31) / 32) * ((N + 31) / 32) * nbatch;
+  if (tile == 0) tile = (t_big >= 2L * cus) ? 2 : 1;
+  const long tiles = tile == 2 ? t_big : t_small;
+  if (splitk == 0) {
+    splitk = 1;
+    if (tiles < 2L * cus && K >= 256) {
+      splitk = (int)((3L * cus + tiles - 1) / tiles);
+      const int maxs = K / 128;                      // keep >= 4 k-tiles per split
+      if (splitk > maxs) splitk = maxs;
+      if (splitk < 1) splitk = 1;
+    }
+  }
+  int kchunk = ((K + splitk - 1) / splitk + BK - 1) / BK * BK;
+  splitk = (K + kchunk - 1) / kchunk;
+  if (splitk > 1 && (!ws || (size_t)nbatch * splitk * M * N * sizeof(float) > ws_bytes)) return DRQ_EWS;
+  GemmArgs g;
+  g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.a_bs = a_bs; g.b_bs = b_bs; g.c_bs = c_bs; g.M = M; g.N = N; g.K = K;
+  g.nbatch = nbatch; g.splitk = splitk; g.kchunk = kchunk; g.part = ws;
+  g.ep = Epilogue{bias, aux, bias_bs, aux_bs, ldaux, relu, scatter_hw};
+  auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  bool v4 = (K % 4 == 0);
+  if (a_kc) v4 = v4 && al16(A) && lda % 4 == 0 && a_bs % 4 == 0;
+  if (b_kc) v4 = v4 && al16(B) && ldb % 4 == 0 && b_bs % 4 == 0;
+  if (!a_kc && !b_kc) v4 = false;
+  return tile == 2 ? dispatch<2, 2>(g, a_kc, b_kc, v4, st) : dispatch<1, 1>(g, a_kc, b_kc, v4, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,189 @@
+"""Host side of the HIP update step: parameter/gradient/Adam arenas, the static workspace, the
+DrqStep descriptor and the data-parallel exchange points.  Memory is allocated and owned by
+PyTorch-ROCm; the library only ever sees raw pointers."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import DrqStep, check, ptr
+
+NETS = ("enc", "critic", "actor", "target")
+
+
+class FlatAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics (defaults; drqv2.py:148-150) over one contiguous segment of the
+    parameter arena.  `step()` is one fused launch; inside DrQV2Agent.update() the same kernel is
+    issued by the step library, which advances `t` through `begin_step()`."""
+
+    def __init__(self, params, lr, seg_p, seg_g, seg_m, seg_v):
+        super().__init__(list(params), dict(lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False))
+        self._p, self._g, self._m, self._v = seg_p, seg_g, seg_m, seg_v
+        self.t = 0
+
+    @property
+    def lr(self):
+        return self.param_groups[0]["lr"]
+
+    def begin_step(self):
+        self.t += 1
+        return self.t
+
+    def zero_grad(self, set_to_none=True):
+        # gradients are overwritten (never accumulated) by the backward kernels
+        return None
+
+    @torch.no_grad()
+    def step(self, closure=None, gscale=1.0, tgt=None, tau=0.0):
+        from . import ops
+        ops.adam_flat(self._p, self._g, self._m, self._v, self.lr, self.begin_step(), gscale, tgt, tau)
+
+    # snapshot helpers (train.py:192-204 pickles the agent)
+    def export_state(self):
+        return {"t": self.t, "lr": self.lr, "m": self._m.detach().cpu().clone(), "v": self._v.detach().cpu().clone()}
+
+    def import_state(self, st):
+        self.t = int(st["t"])
+        self.param_groups[0]["lr"] = st["lr"]
+        self._m.copy_(st["m"])
+        self._v.copy_(st["v"])
+
+
+class StepEngine:
+    def __init__(self, encoder, actor, critic, critic_target, obs_shape, action_dim, feature_dim, hidden_dim, lr,
+                 device):
+        self.device = torch.device(device)
+        self.C, self.A, self.F, self.H = int(obs_shape[0]), int(action_dim), int(feature_dim), int(hidden_dim)
+        self.layout = _lib.param_layout(self.C, self.A, self.F, self.H)
+        total = self.layout["total"]
+        dev = self.device
+        self.params = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.grads = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.adam_m = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.adam_v = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.modules = {"enc": encoder, "critic": critic, "actor": actor, "target": critic_target}
+        for name, mod in self.modules.items():
+            self._adopt(name, mod)
+        seg = self.layout["seg"]
+        mk = lambda n, mod: FlatAdam(mod.parameters(), lr, *(a[seg[n][0]:seg[n][1]] for a in
+                                                            (self.params, self.grads, self.adam_m, self.adam_v)))
+        self.encoder_opt = mk("enc", encoder)
+        self.actor_opt = mk("actor", actor)
+        self.critic_opt = mk("critic", critic)
+        self._ws = None
+        self._ws_B = None
+        self._base = None
+        self.sums = torch.zeros(8, device=dev, dtype=torch.float32)
+        self.pg = None            # torch.distributed process group for data parallelism
+        self.world = 1
+        self.rank = 0
+
+    # ---- arenas --------------------------------------------------------------------------
+    def _adopt(self, name, mod):
+        """Move the module's parameters into the arena (parameters() order) and re-point them."""
+        offs = self.layout[name]
+        plist = list(mod.parameters())
+        assert len(plist) == len(offs), (name, len(plist), len(offs))
+        with torch.no_grad():
+            for p, off in zip(plist, offs):
+                n = p.numel()
+                view = self.params[off:off + n].view(p.shape)
+                view.copy_(p.data.to(torch.float32))
+                p.data = view
+                if name != "target":
+                    p.grad = self.grads[off:off + n].view(p.shape)
+        b, e = self.layout["seg"][name]
+        mod._drq_segment = self.params[b:e]
+
+    # ---- workspace -----------------------------------------------------------------------
+    def _workspace(self, B):
+        if self._ws is None or self._ws_B != B:
+            lib = _lib.load()
+            nbytes = lib.drq_step_ws_bytes(B, self.C, self.A, self.F, self.H)
+            if nbytes == 0:
+                raise _lib.DrqError("drq_step_ws_bytes: unsupported dimensions")
+            self._ws = None
+            self._ws = torch.zeros(nbytes // 4, device=self.device, dtype=torch.float32)  # zero: padded borders
+            self._ws_B = B
+        return self._ws
+
+    def ws_view(self, name, B, shape):
+        """Named workspace buffer as a tensor view (tests / tools)."""
+        lib = _lib.load()
+        off = lib.drq_step_ws_offset(B, self.C, self.A, self.F, self.H, _lib.WS_IDS.index(name))
+        n = 1
+        for s in shape:
+            n *= s
+        return self._workspace(B)[off:off + n].view(shape)
+
+    def base_grid(self):
+        if self._base is None:
+            from .ops import aug_base_grid
+            self._base = aug_base_grid(84, 4, self.device)
+        return self._base
+
+    # ---- data parallel -------------------------------------------------------------------
+    def enable_data_parallel(self, process_group=None):
+        import torch.distributed as dist
+        self.pg = process_group if process_group is not None else dist.group.WORLD
+        self.world = dist.get_world_size(self.pg)
+        self.rank = dist.get_rank(self.pg)
+
+    def _allreduce(self, t):
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+
+    # ---- the step ------------------------------------------------------------------------
+    def make_desc(self, B_local, B_global, std, clip, tau, steps):
+        if self.device.type != "cuda":
+            raise _lib.DrqError("DrQV2Agent.update/act need the GPU: the HIP path has no CPU fallback")
+        ws = self._workspace(B_local)
+        d = DrqStep()
+        d.B, d.global_B, d.C, d.A, d.F, d.H = B_local, B_global, self.C, self.A, self.F, self.H
+        d.base_grid = ptr(self.base_grid())
+        d.params, d.grads, d.adam_m, d.adam_v = ptr(self.params), ptr(self.grads), ptr(self.adam_m), ptr(self.adam_v)
+        d.ws, d.ws_bytes = ptr(ws), ws.numel() * 4
+        d.sums = ptr(self.sums)
+        d.lr, d.tau = float(self.critic_opt.lr), float(tau)
+        d.std, d.clip = float(std), float(clip)
+        d.step_critic, d.step_enc, d.step_actor = steps
+        d.gscale = 1.0 / self.world
+        d.stream = torch.cuda.current_stream().cuda_stream
+        return d
+
+    def update(self, obs, action, reward, discount, next_obs, shift_obs, shift_next, noise_critic, noise_actor, std,
+               clip, tau, B_global=None):
+        """All tensors are this rank's shard, on the GPU.  Returns the 8-float sums tensor (device)."""
+        lib = _lib.load()
+        B = obs.shape[0]
+        B_global = B * self.world if B_global is None else B_global
+        steps = (self.critic_opt.begin_step(), self.encoder_opt.begin_step(), self.actor_opt.begin_step())
+        d = self.make_desc(B, B_global, std, clip, tau, steps)
+        keep = (obs, action, reward, discount, next_obs, shift_obs, shift_next, noise_critic, noise_actor)
+        d.obs, d.next_obs = ptr(obs), ptr(next_obs)
+        d.action, d.reward, d.discount = ptr(action), ptr(reward), ptr(discount)
+        d.shift_obs, d.shift_next = ptr(shift_obs), ptr(shift_next)
+        d.noise_critic, d.noise_actor = ptr(noise_critic), ptr(noise_actor)
+        ref = ctypes.byref(d)
+        if self.world == 1:
+            check(lib.drq_update_phase(ref, -1), "drq_update_phase")
+        else:
+            seg = self.layout["seg"]
+            check(lib.drq_update_phase(ref, 0), "drq_update_phase(0)")
+            self._allreduce(self.grads[seg["enc"][0]:seg["critic"][1]])       # bucket 1: encoder + critic
+            check(lib.drq_update_phase(ref, 1), "drq_update_phase(1)")
+            self._allreduce(self.grads[seg["actor"][0]:seg["actor"][1]])      # bucket 2: actor
+            self._allreduce(self.sums)
+            check(lib.drq_update_phase(ref, 2), "drq_update_phase(2)")
+        del keep
+        return self.sums
+
+    def act_forward(self, obs_u8):
+        """obs u8 [n,C,84,84] on the GPU -> mu [n,A]."""
+        lib = _lib.load()
+        n = obs_u8.shape[0]
+        B = self._ws_B if (self._ws_B is not None and 2 * self._ws_B >= n) else max(1, (n + 1) // 2)
+        d = self.make_desc(B, B, 1.0, 0.0, 0.0, (1, 1, 1))
+        mu = torch.empty((n, self.A), device=self.device, dtype=torch.float32)
+        check(lib.drq_act_forward(ctypes.byref(d), ptr(obs_u8), n, ptr(mu)), "drq_act_forward")
+        return mu

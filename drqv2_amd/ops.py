@@ -1,0 +1,187 @@
+"""Thin tensor-level wrappers over the C ABI (include/drqv2_hip.h): shape checks on the host, raw
+device pointers into the library, work enqueued on torch's current stream.  GPU tensors only."""
+import torch
+
+from . import _lib
+from ._lib import check, ptr
+
+ENC_H = (84, 41, 39, 37, 35)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need(t, dtype=torch.float32, name="tensor"):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise _lib.DrqError(f"{name}: a GPU tensor is required (the HIP path has no CPU fallback)")
+    if t.dtype != dtype or not t.is_contiguous():
+        raise _lib.DrqError(f"{name}: contiguous {dtype} required, got {t.dtype} contiguous={t.is_contiguous()}")
+    return t
+
+
+def aug_base_grid(h, pad, device):
+    """The table torch.linspace gives the reference on the same device (drqv2.py:24-29)."""
+    S = h + 2 * pad
+    eps = 1.0 / S
+    return torch.linspace(-1.0 + eps, 1.0 - eps, S, device=device, dtype=torch.float32)[:h].contiguous()
+
+
+def random_shifts_aug(x, shift, pad=4, base=None, fuse_norm=False):
+    """x: u8 or f32 [n,c,h,h]; shift: f32 [n,1,1,2] or [n,2] (the torch.randint draw)."""
+    lib = _lib.load()
+    n, c, h, w = x.shape
+    assert h == w
+    shift = _need(shift.reshape(n, 2), name="shift")
+    base = aug_base_grid(h, pad, x.device) if base is None else _need(base, name="base")
+    out = torch.empty((n, c, h, w), device=x.device, dtype=torch.float32)
+    if x.dtype == torch.uint8:
+        _need(x, torch.uint8, "obs")
+        check(lib.drq_aug_fwd(ptr(x), ptr(shift), ptr(base), ptr(out), n, c, h, pad, int(fuse_norm), _stream()),
+              "drq_aug_fwd")
+    else:
+        _need(x, name="obs")
+        if fuse_norm:
+            raise _lib.DrqError("fuse_norm needs uint8 input")
+        check(lib.drq_aug_fwd_f32(ptr(x), ptr(shift), ptr(base), ptr(out), n, c, h, pad, _stream()),
+              "drq_aug_fwd_f32")
+    return out
+
+
+def u8_normalize(x):
+    lib = _lib.load()
+    _need(x, torch.uint8, "obs")
+    y = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    check(lib.drq_u8_normalize(ptr(x), ptr(y), x.numel(), _stream()), "drq_u8_normalize")
+    return y
+
+
+def conv3x3_fwd(x, w, b, stride, relu=True):
+    lib = _lib.load()
+    _need(x, name="x"), _need(w, name="w"), _need(b, name="b")
+    nb, cin, hin, _ = x.shape
+    hout = (hin - 3) // stride + 1
+    y = torch.empty((nb, 32, hout, hout), device=x.device, dtype=torch.float32)
+    check(lib.drq_conv3x3_fwd(ptr(x), ptr(w), ptr(b), ptr(y), nb, cin, hin, stride, int(relu), 32 * hout * hout,
+                              hout * hout, hout, 0, _stream()), "drq_conv3x3_fwd")
+    return y
+
+
+def conv3x3_dgrad(dy_pad, w, mask):
+    """dy_pad [nb,32,hout+4,hout+4] (zero border of 2) -> dx [nb,32,hout+2,hout+2] * (mask>0)."""
+    lib = _lib.load()
+    _need(dy_pad, name="dy_pad"), _need(w, name="w")
+    nb, _, hp, _ = dy_pad.shape
+    hout = hp - 4
+    hin = hout + 2
+    if mask is not None:
+        _need(mask, name="mask")
+        assert tuple(mask.shape) == (nb, 32, hin, hin)
+    dx = torch.empty((nb, 32, hin, hin), device=dy_pad.device, dtype=torch.float32)
+    check(lib.drq_conv3x3_dgrad(ptr(dy_pad), ptr(w), ptr(mask), ptr(dx), nb, hout, 32 * hin * hin, hin * hin, hin, 0,
+                                _stream()), "drq_conv3x3_dgrad")
+    return dx
+
+
+def conv3x3_wgrad(x, dy, stride):
+    """x [nb,cin,hin,hin], dy [nb,32,hout,hout] (any strides with unit x-stride) -> dw, db."""
+    lib = _lib.load()
+    _need(x, name="x")
+    if not (dy.is_cuda and dy.dtype == torch.float32 and dy.stride(3) == 1):
+        raise _lib.DrqError("dy: GPU fp32 with unit innermost stride required")
+    nb, cin, hin, _ = x.shape
+    dw = torch.empty((32, cin, 3, 3), device=x.device, dtype=torch.float32)
+    db = torch.empty((32,), device=x.device, dtype=torch.float32)
+    nbytes = lib.drq_conv3x3_wgrad_ws_bytes()
+    ws = torch.empty((nbytes // 4,), device=x.device, dtype=torch.float32)
+    check(lib.drq_conv3x3_wgrad(ptr(x), dy.data_ptr(), ptr(dw), ptr(db), nb, cin, hin, stride, dy.stride(0),
+                                dy.stride(1), dy.stride(2), 0, ptr(ws), nbytes, _stream()), "drq_conv3x3_wgrad")
+    return dw, db
+
+
+def gemm(A, a_kc, B, b_kc, M, N, K, lda=None, ldb=None, bias=None, relu=False, aux=None, nbatch=1, a_bs=0,
+         b_bs=0, c_bs=None, bias_bs=0, aux_bs=0, tile=0, splitk=0, out=None, ldc=None):
+    lib = _lib.load()
+    dev = A.device
+    lda = lda if lda is not None else (K if a_kc else M)
+    ldb = ldb if ldb is not None else (K if b_kc else N)
+    ldc = ldc if ldc is not None else N
+    c_bs = c_bs if c_bs is not None else M * N
+    if out is None:
+        out = torch.empty((nbatch, M, N) if nbatch > 1 else (M, N), device=dev, dtype=torch.float32)
+    ws = torch.empty((16 * 1024 * 1024,), device=dev, dtype=torch.float32)
+    check(lib.drq_gemm_f32(ptr(A), lda, int(a_kc), ptr(B), ldb, int(b_kc), ptr(out), ldc, M, N, K, nbatch, a_bs, b_bs,
+                           c_bs, ptr(bias), bias_bs, int(relu), ptr(aux), (aux.shape[-1] if aux is not None else 0),
+                           aux_bs, 0, tile, splitk, ptr(ws), ws.numel() * 4, _stream()), "drq_gemm_f32")
+    return out
+
+
+def linear_fwd(x, w, b, relu=False, **kw):
+    M, K = x.shape
+    N = w.shape[0]
+    return gemm(x, True, w, True, M, N, K, bias=b, relu=relu, **kw)
+
+
+def linear_dgrad(dy, w, mask=None, **kw):
+    M, K = dy.shape           # K = out features
+    N = w.shape[1]
+    return gemm(dy, True, w, False, M, N, K, aux=mask, **kw)
+
+
+def linear_wgrad(dy, x, **kw):
+    Brows, N = dy.shape
+    K = x.shape[1]
+    dw = gemm(dy, False, x, False, N, K, Brows, lda=N, ldb=K, **kw)
+    lib = _lib.load()
+    db = torch.empty((N,), device=dy.device, dtype=torch.float32)
+    check(lib.drq_colsum(ptr(dy), N, 0, ptr(db), 0, Brows, N, 1, _stream()), "drq_colsum")
+    return dw, db
+
+
+def ln_tanh_fwd(z, gamma, beta, save=True):
+    lib = _lib.load()
+    rows, F = z.shape
+    out = torch.empty_like(z)
+    xhat = torch.empty_like(z) if save else None
+    rstd = torch.empty((rows,), device=z.device, dtype=torch.float32) if save else None
+    check(lib.drq_ln_tanh_fwd(ptr(z), F, ptr(gamma), ptr(beta), ptr(out), F, ptr(xhat), ptr(rstd), rows, F, _stream()),
+          "drq_ln_tanh_fwd")
+    return out, xhat, rstd
+
+
+def ln_tanh_bwd(dh, h, xhat, rstd, gamma):
+    lib = _lib.load()
+    rows, F = dh.shape
+    dz, dln = torch.empty_like(dh), torch.empty_like(dh)
+    dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
+    check(lib.drq_ln_tanh_bwd(ptr(dh), F, None, 0, ptr(h), F, ptr(xhat), ptr(rstd), ptr(gamma), ptr(dz), ptr(dln),
+                              ptr(dg), ptr(db), rows, F, _stream()), "drq_ln_tanh_bwd")
+    return dz, dg, db
+
+
+def trunc_normal_sample(pre_tanh, noise, std, clip):
+    lib = _lib.load()
+    B, A = pre_tanh.shape
+    mu, a = torch.empty_like(pre_tanh), torch.empty_like(pre_tanh)
+    check(lib.drq_trunc_normal_sample(ptr(pre_tanh), ptr(noise), float(std), float(clip if clip is not None else 0.0),
+                                      int(clip is not None), ptr(mu), ptr(a), A, B, A, _stream()),
+          "drq_trunc_normal_sample")
+    return mu, a
+
+
+def adam_flat(p, g, m, v, lr, step, gscale=1.0, tgt=None, tau=0.0):
+    lib = _lib.load()
+    check(lib.drq_adam_flat(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), int(step), float(gscale), ptr(tgt),
+                            float(tau), _stream()), "drq_adam_flat")
+
+
+def ema_flat(p, t, tau):
+    lib = _lib.load()
+    check(lib.drq_ema_flat(ptr(p), ptr(t), p.numel(), float(tau), _stream()), "drq_ema_flat")
+
+
+def tanh(x):
+    lib = _lib.load()
+    y = torch.empty_like(x)
+    check(lib.drq_tanh(ptr(x), ptr(y), x.numel(), _stream()), "drq_tanh")
+    return y

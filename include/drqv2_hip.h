@@ -1,0 +1,159 @@
+/* libdrqv2_hip.so -- C ABI of the MI355X-native DrQ-v2 update path.
+ *
+ * The reference (johannah/drqv2) has no native boundary of its own: DrQV2Agent.update()
+ * (drqv2.py:230-262) reaches ATen/cuDNN through torch.nn / torch.optim.  Each entry point below
+ * replaces the ATen kernels behind the cited reference lines; the Python host (drqv2.py, utils.py at
+ * the repo root, drqv2_amd/) binds them with ctypes.  Conventions:
+ *   - plain pointers + sizes; every pointer is DEVICE memory owned by the caller (PyTorch-ROCm);
+ *   - every call is enqueued on `stream` (a hipStream_t, passed as void*), nothing synchronises;
+ *   - return 0 = ok, <0 = argument/shape/workspace error, >0 = hipError_t of the launch;
+ *   - no global state, no allocation; tensors are fp32 row-major / NCHW unless stated.
+ */
+#ifndef DRQV2_HIP_H
+#define DRQV2_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* drq_stream_t; /* hipStream_t */
+
+#define DRQ_OK 0
+#define DRQ_EARG (-1)
+#define DRQ_EWS (-2)
+
+int drq_abi_version(void);
+
+/* ---- RandomShiftsAug.forward (drqv2.py:19-45) [+ Encoder's obs/255-0.5, drqv2.py:64, if fuse_norm]
+ * obs u8 [n][c][hw][hw]; shift_xy f32 [n][2] = the torch.randint(0,2*pad+1,(n,1,1,2)) draw (x,y);
+ * base_grid f32 [hw] = linspace(-1+1/S,1-1/S,S)[:hw]; out f32 [n][c][hw][hw]. */
+int drq_aug_fwd(const uint8_t* obs, const float* shift_xy, const float* base_grid, float* out, int n, int c,
+                int hw, int pad, int fuse_norm, drq_stream_t stream);
+int drq_aug_fwd_f32(const float* x, const float* shift_xy, const float* base_grid, float* out, int n, int c,
+                    int hw, int pad, drq_stream_t stream);
+
+/* ---- Encoder conv layers (drqv2.py:55-59): Conv2d(cin,32,3,stride)+ReLU, 32 output channels.
+ * Supported (cin,hin,stride): (9,84,2) (32,41,1) (32,39,1) (32,37,1).  y element (b,co,oy,ox) is
+ * written at y[y_off + b*y_bs + co*y_cs + oy*y_rs + ox]. */
+int drq_conv3x3_fwd(const float* x, const float* w, const float* bias, float* y, int nb, int cin, int hin,
+                    int stride, int relu, long y_bs, long y_cs, long y_rs, long y_off, drq_stream_t stream);
+/* autograd of the same layers.  dy_pad = gradient w.r.t. the pre-activation, stored zero-padded by 2:
+ * [nb][32][hout+4][hout+4].  dx (size hout+2) = conv_transpose(dy, w) * (mask > 0), strided store. */
+int drq_conv3x3_dgrad(const float* dy_pad, const float* w, const float* mask, float* dx, int nb, int hout,
+                      long dx_bs, long dx_cs, long dx_rs, long dx_off, drq_stream_t stream);
+/* dw [32][cin][3][3], db [32]; dy addressed as dy[dy_off + b*dy_bs + co*dy_cs + oy*dy_rs + ox]. */
+int drq_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, int nb, int cin, int hin,
+                      int stride, long dy_bs, long dy_cs, long dy_rs, long dy_off, float* ws, size_t ws_bytes,
+                      drq_stream_t stream);
+size_t drq_conv3x3_wgrad_ws_bytes(void);
+
+/* ---- nn.Linear forward / backward (drqv2.py:74-81,100-111) as one strided, batched GEMM:
+ *   C[b][m][n] = epi( sum_k A_b(m,k) * B_b(k,n) ),  epi(v) = relu?(v + bias[n]) * (aux[m][n] > 0)?
+ *   a_kc: A(m,k)=A[m*lda+k] else A[k*lda+m];  b_kc: B(k,n)=B[n*ldb+k] else B[k*ldb+n].
+ *   scatter_hw>0: C index = zero-padded (pad 2) NCHW gradient layout of a [M][32*hw*hw] feature map.
+ *   tile: 0 auto, 1 = 32x32, 2 = 64x64 block tile; splitk: 0 auto (needs ws). */
+int drq_gemm_f32(const float* A, long lda, int a_kc, const float* B, long ldb, int b_kc, float* C, long ldc,
+                 int M, int N, int K, int nbatch, long a_bs, long b_bs, long c_bs, const float* bias, long bias_bs,
+                 int relu, const float* aux, int ldaux, long aux_bs, int scatter_hw, int tile, int splitk,
+                 float* ws, size_t ws_bytes, drq_stream_t stream);
+
+/* ---- nn.LayerNorm(F)+nn.Tanh (drqv2.py:74-75,100-101), eps 1e-5, F <= 256 */
+int drq_ln_tanh_fwd(const float* z, int ldz, const float* gamma, const float* beta, float* out, int ldo,
+                    float* xhat, float* rstd, int rows, int F, drq_stream_t stream);
+int drq_ln_tanh_fwd2(const float* z0, const float* z1, int ldz, const float* gamma0, const float* beta0,
+                     const float* gamma1, const float* beta1, float* out0, int ldo0, float* out1, int ldo1,
+                     float* xhat0, float* rstd0, float* xhat1, float* rstd1, int rows, int F, drq_stream_t stream);
+int drq_ln_tanh_bwd(const float* dh0, int ld0, const float* dh1, int ld1, const float* h, int ldh,
+                    const float* xhat, const float* rstd, const float* gamma, float* dz, float* dln,
+                    float* dgamma, float* dbeta, int rows, int F, drq_stream_t stream);
+
+/* ---- bias gradients: out[b][n] = sum_m dy[b][m][n] */
+int drq_colsum(const float* dy, long ld, long dy_bs, float* out, long out_bs, int M, int N, int nbatch,
+               drq_stream_t stream);
+
+/* ---- Actor head + utils.TruncatedNormal.sample (drqv2.py:88-92, utils.py:112-126):
+ * mu = tanh(pre_tanh); a = clamp(mu + clamp(noise*std, +-clip), +-(1-1e-6)); a -> a_out[b*lda_out + j]. */
+int drq_trunc_normal_sample(const float* pre_tanh, const float* noise, float std, float clip, int use_clip,
+                            float* mu_out, float* a_out, long lda_out, int B, int A, drq_stream_t stream);
+int drq_copy_cols(const float* src, int ld_src, float* dst, long ld_dst, int B, int A, drq_stream_t stream);
+
+/* ---- update_critic loss (drqv2.py:185-189): y = r + d*min(tq1,tq2); dq_k = 2(q_k-y)*inv_global_B;
+ * sums[0..4] = sum r, sum y, sum q1, sum q2, sum((q1-y)^2+(q2-y)^2) over the LOCAL batch. */
+int drq_td_mse(const float* tq1, const float* tq2, const float* q1, const float* q2, const float* reward,
+               const float* discount, float* dq1, float* dq2, float* sums, int B, float inv_global_B,
+               drq_stream_t stream);
+/* ---- update_actor loss (drqv2.py:212-216,225): sums[5] = sum -min(q1,q2), sums[6] = sum log_prob */
+int drq_actor_loss(const float* q1, const float* q2, const float* a, long lda, const float* mu, float std,
+                   float* dq1, float* dq2, float* sums, int B, int A, float inv_global_B, drq_stream_t stream);
+int drq_actor_dmu(const float* dha1, const float* dha2, long ld, int col0, const float* mu, float* dpre, int B,
+                  int A, drq_stream_t stream);
+
+/* ---- torch.optim.Adam.step (drqv2.py:148-150,201-202,221; defaults) over a flat arena; optional fused
+ * utils.soft_update_params (utils.py:42-45) into tgt.  g is multiplied by gscale first (1 = exact). */
+int drq_adam_flat(float* p, const float* g, float* m, float* v, long n, double lr, long step, float gscale,
+                  float* tgt, double tau, drq_stream_t stream);
+int drq_ema_flat(const float* p, float* t, long n, double tau, drq_stream_t stream);
+int drq_fill(float* p, long n, float v, drq_stream_t stream);
+/* obs/255-0.5 on raw uint8 frames (drqv2.py:64 as reached from act(), drqv2.py:165-166); y = tanh(x) */
+int drq_u8_normalize(const uint8_t* x, float* y, long n, drq_stream_t stream);
+int drq_tanh(const float* x, float* y, long n, drq_stream_t stream);
+
+/* ---- whole-step entry: DrQV2Agent.update (drqv2.py:230-262) ------------------------------------ */
+typedef struct {
+  int B, global_B, C, A, F, H;
+  const uint8_t* obs;        /* [B][C][84][84] */
+  const uint8_t* next_obs;
+  const float* action;       /* [B][A] */
+  const float* reward;       /* [B] */
+  const float* discount;     /* [B] */
+  const float* shift_obs;    /* [B][2] */
+  const float* shift_next;
+  const float* noise_critic; /* [B][A] */
+  const float* noise_actor;
+  const float* base_grid;    /* [84] */
+  float* params;             /* arenas laid out by drq_param_layout */
+  float* grads;
+  float* adam_m;
+  float* adam_v;
+  float* ws;                 /* drq_step_ws_bytes(), zero-initialised once */
+  size_t ws_bytes;
+  float* sums;               /* [8] local partial sums of the metrics */
+  double lr, tau;
+  float std, clip;
+  long step_critic, step_enc, step_actor; /* 1-based Adam step numbers of THIS update */
+  float gscale;              /* 1/world_size when gradients were SUM-reduced, else 1 */
+  drq_stream_t stream;
+} DrqStep;
+
+/* Parameter arena: tensors in parameters() order of encoder, critic, actor, critic_target, each start
+ * aligned to 64 floats.  out[] receives, in this order: encoder 8 offsets, critic 16, actor 10,
+ * critic_target 16, then [enc_beg, enc_end, critic_beg, critic_end, actor_beg, actor_end, target_beg,
+ * target_end], then total.  Returns the number of longs written (59) or <0. */
+int drq_param_layout(int C, int A, int F, int H, long* out, int cap);
+#define DRQ_PARAM_LAYOUT_LEN 59
+
+size_t drq_step_ws_bytes(int B, int C, int A, int F, int H);
+/* offsets (in floats) of named buffers inside ws, for tests and tools; ids below. */
+long drq_step_ws_offset(int B, int C, int A, int F, int H, int buffer_id);
+enum {
+  DRQ_WS_AUG = 0, DRQ_WS_ACT1, DRQ_WS_ACT2, DRQ_WS_ACT3, DRQ_WS_FEAT, DRQ_WS_Z_NEXT, DRQ_WS_Z_OBS,
+  DRQ_WS_HA_T, DRQ_WS_HA_C, DRQ_WS_H_AN, DRQ_WS_H_AO, DRQ_WS_Q, DRQ_WS_TQ, DRQ_WS_DQ, DRQ_WS_MU_O,
+  DRQ_WS_DY4, DRQ_WS_DY3, DRQ_WS_DY2, DRQ_WS_DY1, DRQ_WS_DZ_C, DRQ_WS_DZ_A, DRQ_WS_HA_C2, DRQ_WS_NBUF_PUBLIC
+};
+
+/* phase 0: aug, encoder fwd, critic loss + backward  (leaves encoder+critic grads, sums[0..4])
+ * phase 1: Adam(critic)+Polyak, Adam(encoder), actor loss + backward (actor grads, sums[5..6])
+ * phase 2: Adam(actor)
+ * phase -1: all three back to back (single GPU).  The data-parallel host all-reduces between phases. */
+int drq_update_phase(const DrqStep* s, int phase);
+
+/* Encoder+actor forward for DrQV2Agent.act (drqv2.py:164-175): obs u8 [n][C][84][84] -> mu [n][A]
+ * (n <= 2*B; uses s->params, s->ws, s->stream only; must not run between the phases of an update). */
+int drq_act_forward(const DrqStep* s, const uint8_t* obs, int n, float* mu_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,246 @@
+"""Step-level parity: DrQV2Agent.update() on the GPU (HIP path, through libdrqv2_hip.so) against the
+CPU oracle on identical replay samples, shifts and noise, and against the reference's own outputs
+(tests/golden/steps.json.gz).  Tolerances: SURVEY.md App. B / BASELINE.md section 4."""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from drqv2_amd import synth
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+CASES = {
+    # name: C, A, F, H, B, lr, sched, wseed, bseed, updates, step0, smooth   (same as make_golden.py)
+    "cheetah_b8": dict(C=9, A=6, F=50, H=1024, B=8, lr=1e-4, sched="linear(1.0,0.1,500000)", wseed=0, bseed=0,
+                       updates=3, step0=0, smooth=True),
+    "humanoid_b4": dict(C=9, A=21, F=100, H=1024, B=4, lr=8e-5, sched="linear(1.0,0.1,2000000)", wseed=1, bseed=10,
+                        updates=2, step0=1000, smooth=True),
+    "cartpole_b32": dict(C=9, A=1, F=50, H=1024, B=32, lr=1e-4, sched="linear(1.0,0.1,100000)", wseed=2, bseed=20,
+                         updates=2, step0=50000, smooth=False),
+    "small_h64_b6": dict(C=9, A=3, F=20, H=64, B=6, lr=1e-3, sched="0.2", wseed=3, bseed=30, updates=3, step0=0,
+                         smooth=True),
+}
+
+
+def nerr(a, b):
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def make_agent(cfg):
+    import drqv2
+    ag = drqv2.DrQV2Agent((cfg["C"], 84, 84), (cfg["A"],), "cuda", cfg["lr"], cfg["F"], cfg["H"], 0.01, 2000, 2,
+                          cfg["sched"], 0.3, True)
+    enc, actor, critic = synth.make_weights(cfg["C"], cfg["A"], cfg["F"], cfg["H"], cfg["wseed"])
+    ag.encoder.load_state_dict(enc)
+    ag.actor.load_state_dict(actor)
+    ag.critic.load_state_dict(critic)
+    ag.critic_target.load_state_dict(critic)
+    return ag
+
+
+def make_oracle(cfg, dtype):
+    from oracle import drq_oracle as O
+    enc, actor, critic = synth.make_weights(cfg["C"], cfg["A"], cfg["F"], cfg["H"], cfg["wseed"])
+    return O.OracleAgent(enc, actor, critic, cfg["lr"], stddev_schedule=cfg["sched"], dtype=dtype)
+
+
+def run_hip(ag, cfg, u):
+    batch = synth.make_batch(cfg["B"], cfg["A"], cfg["C"], seed=cfg["bseed"] + u, smooth=cfg["smooth"])
+    draws = synth.make_draws(cfg["B"], cfg["A"], seed=cfg["bseed"] + u)
+    ag._draw_hook = lambda n, A: tuple(t.float().cuda() for t in draws)
+    m = ag.update(iter([tuple(x.numpy() for x in batch)]), cfg["step0"] + 2 * u)
+    return m, batch, draws
+
+
+@pytest.fixture(scope="module")
+def golden_steps():
+    with gzip.open(os.path.join(G, "steps.json.gz"), "rt") as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_update_matches_oracle(name, golden_steps):
+    cfg = CASES[name]
+    from oracle import drq_oracle as O
+    ag = make_agent(cfg)
+    o32, o64 = make_oracle(cfg, torch.float32), make_oracle(cfg, torch.float64)
+    base = O.aug_base_grid(84, 4)
+    for u in range(cfg["updates"]):
+        step = cfg["step0"] + 2 * u
+        m, batch, (sh_o, sh_n, n_c, n_a) = run_hip(ag, cfg, u)
+        # both oracles get the same fp32 augmented frames (the aug op itself is pinned in test_hip_ops)
+        ov = (O.random_shifts_aug(batch[0].float(), sh_o, 4, base), O.random_shifts_aug(batch[4].float(), sh_n, 4, base))
+        m32 = o32.update(batch, step, sh_o, sh_n, n_c, n_a, aug_override=ov, keep=True)
+        m64 = o64.update(batch, step, sh_o, sh_n, n_c, n_a, aug_override=ov, keep=True)
+        assert list(m.keys()) == list(m64.keys())
+        # later updates inherit the sign-SGD amplification of Adam at t=1 (SURVEY finding 3)
+        tol = 1e-5 if u == 0 else 3e-3
+        for k in m64:
+            assert m[k] == pytest.approx(m64[k], rel=tol, abs=tol), (u, k, m[k], m32[k], m64[k])
+        if u > 0:
+            continue
+        B = cfg["B"]
+        eng = ag._engine
+        # forward: encoder features of both views
+        feat = eng.ws_view("FEAT", B, (2 * B, 39200))
+        assert nerr(feat[:B], o64.last["feat"]) <= 2e-6
+        assert nerr(feat[B:], o64.last["feat_next"]) <= 2e-6
+        # gradients (first update, identical upstream): error vs fp64 no worse than the fp32 oracle's own
+        for nm, mod, key in (("enc", ag.encoder, "g_enc"), ("critic", ag.critic, "g_critic"),
+                             ("actor", ag.actor, "g_actor")):
+            for (pn, p), g64, g32 in zip(mod.named_parameters(), o64.last[key].values(), o32.last[key].values()):
+                e_hip, e_o32 = nerr(p.grad, g64), nerr(g32, g64)
+                lim = max(2.0 * e_o32, 2e-5 if nm != "actor" else 2e-3)
+                assert e_hip <= lim, (nm, pn, e_hip, e_o32)
+    # reference's own first-update metrics (real grid_sample aug), fixtures from make_golden.py
+    ref = golden_steps[name]["ref_fp32_aug"][0]["metrics"]
+    ag2 = make_agent(cfg)
+    m0, _, _ = run_hip(ag2, cfg, 0)
+    for k, v in ref.items():
+        assert m0[k] == pytest.approx(v, rel=2e-5, abs=2e-5), (k, m0[k], v)
+
+
+def test_params_after_update_match_oracle_with_same_grads():
+    """Adam + Polyak inside the step: feed the oracle's Adam the HIP gradients -> identical parameters."""
+    cfg = CASES["small_h64_b6"]
+    from oracle import drq_oracle as O
+    ag = make_agent(cfg)
+    before = {n: {k: v.detach().cpu().clone() for k, v in getattr(ag, n).state_dict().items()}
+              for n in ("encoder", "critic", "actor", "critic_target")}
+    run_hip(ag, cfg, 0)
+    for n in ("encoder", "critic", "actor"):
+        mod = getattr(ag, n)
+        for (k, p) in mod.named_parameters():
+            p0 = before[n][k].clone()
+            m, v = torch.zeros_like(p0), torch.zeros_like(p0)
+            O.adam_step(p0, p.grad.detach().cpu(), m, v, 1, cfg["lr"])
+            assert torch.equal(p.detach().cpu(), p0), (n, k)
+            if n == "critic":
+                t0 = before["critic_target"][k].clone()
+                O.polyak(p0, t0, 0.01)
+                assert torch.equal(dict(ag.critic_target.named_parameters())[k].detach().cpu(), t0), k
+
+
+def test_gating_and_metric_keys():
+    cfg = CASES["small_h64_b6"]
+    ag = make_agent(cfg)
+    assert ag.update(iter([]), 1) == {}
+    m, _, _ = run_hip(ag, cfg, 0)
+    with open(os.path.join(G, "interface.json")) as f:
+        iface = json.load(f)
+    assert list(m.keys()) == iface["metric_keys"]
+    assert all(isinstance(v, float) for v in m.values())
+    ag.use_tb = False
+    assert run_hip(ag, cfg, 1)[0] == {}
+
+
+def test_rng_draw_order_matches_reference():
+    """Without the hook, update() consumes the global generator like the reference."""
+    cfg = CASES["small_h64_b6"]
+    with open(os.path.join(G, "interface.json")) as f:
+        trace_ref = json.load(f)["rng_trace"]
+    ag = make_agent(cfg)
+    calls = []
+    import drqv2
+    real_randint, real_sn = torch.randint, drqv2._standard_normal
+
+    def t_randint(*a, **k):
+        calls.append(["randint", list(k.get("size", ()))])
+        return real_randint(*a, **k)
+
+    def t_sn(shape, dtype, device):
+        calls.append(["standard_normal", list(shape)])
+        return real_sn(shape, dtype=dtype, device=device)
+
+    torch.randint, drqv2._standard_normal = t_randint, t_sn
+    try:
+        batch = synth.make_batch(4, 3, 9, seed=0)
+        ag.update(iter([tuple(x.numpy() for x in batch)]), 0)
+    finally:
+        torch.randint, drqv2._standard_normal = real_randint, real_sn
+    want = [[k, [4 if d == 4 else d for d in s]] for k, s in trace_ref]
+    got = [[k, s] for k, s in calls]
+    assert [c[0] for c in got] == [c[0] for c in want]
+    assert got[0][1] == [4, 1, 1, 2] and got[2][1] == [4, 3]
+    # same seed -> same shifts as the reference call on the same device
+    torch.manual_seed(5)
+    a = ag.aug.draw(16, "cuda")
+    torch.manual_seed(5)
+    b = torch.randint(0, 9, size=(16, 1, 1, 2), device="cuda", dtype=torch.float32)
+    assert torch.equal(a, b)
+
+
+def test_act_matches_oracle():
+    cfg = CASES["cheetah_b8"]
+    ag = make_agent(cfg)
+    o64 = make_oracle(cfg, torch.float64)
+    obs = synth.make_batch(2, cfg["A"], 9, seed=5)[0]
+    a = ag.act(obs[0].numpy(), 5000, True)
+    assert a.dtype == np.float32 and a.shape == (cfg["A"],)
+    ref = o64.act_mean(obs[0]).numpy()
+    assert np.abs(a - ref).max() <= 2e-6
+    torch.manual_seed(3)
+    a1 = ag.act(obs[1].numpy(), 5000, False)
+    assert np.abs(a1).max() <= 1.0 and not np.allclose(a1, ag.act(obs[1].numpy(), 5000, True))
+    a2 = ag.act(obs[1].numpy(), 10, False)          # uniform exploration branch
+    assert a2.shape == (cfg["A"],) and np.abs(a2).max() <= 1.0
+
+
+def test_module_forwards_and_soft_update():
+    import utils
+    cfg = CASES["small_h64_b6"]
+    ag = make_agent(cfg)
+    o64 = make_oracle(cfg, torch.float64)
+    from oracle import drq_oracle as O
+    obs = synth.make_batch(3, cfg["A"], 9, seed=6)[0]
+    feat = ag.encoder(obs.cuda())
+    assert nerr(feat, O.encoder_forward(o64.enc, obs.double())) <= 2e-6
+    dist = ag.actor(feat, 0.3)
+    assert nerr(dist.mean, O.actor_mu(o64.actor, feat.double().cpu())) <= 5e-6
+    act = torch.from_numpy(np.random.RandomState(0).uniform(-1, 1, (3, cfg["A"])).astype(np.float32))
+    q1, q2 = ag.critic(feat, act.cuda())
+    r1, r2 = O.critic_q(o64.critic, feat.double().cpu(), act.double())
+    assert nerr(q1, r1) <= 1e-5 and nerr(q2, r2) <= 1e-5
+    # utils.soft_update_params on arena-backed modules == per-tensor formula
+    with torch.no_grad():
+        for p in ag.critic.parameters():
+            p.add_(0.01)
+    want = [O_t.clone() for O_t in (t.detach().cpu() for t in ag.critic_target.parameters())]
+    for w, p in zip(want, ag.critic.parameters()):
+        O.polyak(p.detach().cpu(), w, 0.05)
+    utils.soft_update_params(ag.critic, ag.critic_target, 0.05)
+    for w, t in zip(want, ag.critic_target.parameters()):
+        assert torch.equal(t.detach().cpu(), w)
+
+
+def test_pickle_roundtrip_on_gpu():
+    import io
+    cfg = CASES["small_h64_b6"]
+    ag = make_agent(cfg)
+    run_hip(ag, cfg, 0)
+    buf = io.BytesIO()
+    torch.save({"agent": ag}, buf)
+    buf.seek(0)
+    ag2 = torch.load(buf, weights_only=False)["agent"]
+    for a, b in zip(ag.critic.parameters(), ag2.critic.parameters()):
+        assert torch.equal(a, b)
+    assert ag2.critic_opt.t == 1 and torch.equal(ag2._engine.adam_m, ag._engine.adam_m)
+    m1, _, _ = run_hip(ag, cfg, 1)
+    m2, _, _ = run_hip(ag2, cfg, 1)
+    assert m1 == m2          # bit-stable and state fully restored
+
+
+def test_run_to_run_bit_stable():
+    cfg = CASES["small_h64_b6"]
+    a, b = make_agent(cfg), make_agent(cfg)
+    for u in range(2):
+        ma, _, _ = run_hip(a, cfg, u)
+        mb, _, _ = run_hip(b, cfg, u)
+        assert ma == mb
+    assert torch.equal(a._engine.params, b._engine.params)
