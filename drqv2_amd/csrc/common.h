@@ -16,6 +16,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
 
 // Encoder geometry (drqv2.py:55-59): 84 -(k3,s2)-> 41 -> 39 -> 37 -> 35, 32 channels.
 static constexpr int kEncH[5] = {84, 41, 39, 37, 35};

@@ -3,21 +3,25 @@
 // Reference op: nn.Conv2d(Cin,32,3,stride) + ReLU, drqv2.py:55-59, and its autograd
 // backward (dgrad for conv2..4, wgrad for conv1..4).
 //
-// Forward / dgrad kernel (conv3x3_kernel): implicit GEMM  D[cout][pixel] += W[cout][k] * X[k][pixel]
-// with v_mfma_f32_32x32x2_f32 (exact f32 fma chain).  A = weights, held for the whole kernel in
-// registers (one VGPR per k-pair: CP*9 VGPRs, 144 for Cin=32); B = input, one dword per lane per
-// MFMA fetched with a bounds-checked buffer load straight from global memory/L2 (each element is
-// re-used by 32 output channels inside the MFMA and by the 9 taps through L1); a "pixel tile" is 32
-// consecutive output pixels of the flattened (sample,y,x) index, so tiles are always full.
-// k is ordered (channel pair c, tap t): lanes 0-31 take channel 2c, lanes 32-63 channel 2c+1.
-// The dgrad of a stride-1 3x3 valid conv is the same kernel run on the zero-padded (pad 2)
-// output gradient with W transposed and flipped (gather mode 1), epilogue = ReLU mask.
+// Forward / dgrad (conv3x3_kernel): implicit GEMM  D[cout][pixel] += W[cout][k] * X[k][pixel] with
+// v_mfma_f32_32x32x2_f32 (bit-exact f32 fma chain).  k is ordered (channel pair c, tap t): lanes 0-31
+// take channel 2c, lanes 32-63 channel 2c+1.  A = weights, staged ONCE per workgroup into LDS in
+// MFMA-lane order ([step][lane]: one conflict-free ds_read_b32 per MFMA); B = input, one dword per lane
+// per MFMA through a bounds-checked buffer load (each element is re-used by 32 output channels inside
+// the MFMA and by the 3x3 taps through L1).  A "pixel tile" is 32 consecutive output pixels of the
+// flattened (sample,y,x) index, so tiles are always full; a workgroup owns a contiguous run of tiles
+// (neighbouring tiles share input rows in L1/L2).  Few registers per wave (16 accumulators + loads in
+// flight) -> 4+ waves per SIMD hide the memory latency; the MFMA pipe is the only shared resource.
+// The dgrad of a stride-1 3x3 valid conv is the same kernel run on the zero-padded (pad 2) output
+// gradient with W transposed and flipped (gather mode 1), epilogue = ReLU mask.
 //
-// Wgrad kernel (conv3x3_wgrad_kernel): D[cout][col] += dY[cout][pixel] * X[pixel][col], reduction over
-// all B*Hout*Wout pixels.  Each wave owns a contiguous run of output rows, stages the dY row and the
-// three input rows through a wave-private LDS tile (coalesced global loads, odd pitches so that the
-// channel-strided MFMA operand reads are bank-conflict free), keeps all 9 (taps) x 32x32 accumulators
-// in registers, and the partials are reduced deterministically (fixed order, no atomics).
+// Wgrad (conv3x3_wgrad_kernel): D[cout][col] += dY[cout][pixel] * X[pixel][col], reduction over all
+// B*Hout*Wout pixels.  Each wave owns a contiguous run of output rows; per row it stages the dY row and
+// the three input rows through a wave-private LDS tile (row-per-instruction coalesced global loads into
+// registers, issued one row ahead so they fly under the MFMA loop; odd LDS pitches make the
+// channel-strided operand reads bank-conflict free) and keeps all 9 taps x 32x32 accumulators in
+// registers.  Partials: 4 waves -> LDS -> one record per workgroup -> fixed-order reduction kernel
+// (deterministic, no float atomics).
 #include "common.h"
 
 namespace {
@@ -35,102 +39,139 @@ struct ConvArgs {
   int wmode;           // 0 forward gather, 1 dgrad gather (transposed + flipped)
 };
 
-template <int CIN, int HIN, int STRIDE>
-__global__ __launch_bounds__(256, 2) void conv3x3_kernel(ConvArgs a) {
+// BLK = workgroups per CU the kernel is tuned for (8 waves each): 2 -> 4 waves/SIMD (<=128 VGPR)
+template <int CIN, int HIN, int STRIDE, int BLK>
+__global__ __launch_bounds__(512, 2 * BLK) void conv3x3_kernel(ConvArgs a) {
   constexpr int CP = (CIN + 1) / 2;
+  constexpr int NS = CP * 9;                 // MFMA steps per tile
   constexpr int HOUT = (HIN - 3) / STRIDE + 1;
   constexpr int P = HOUT * HOUT;
+  __shared__ float wl[NS * 64];              // A operand, [step][lane]
+
   const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
   const int col = lane & 31;   // MFMA: A row (cout) for the weights, B column (pixel) for the input
   const int half = lane >> 5;  // k parity -> channel parity
-  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
-  const int nwaves = (gridDim.x * 256) >> 6;
 
-  // ---- weights -> registers (A operand), once per wave
-  float wreg[CP * 9];
-#pragma unroll
-  for (int c = 0; c < CP; ++c) {
-    const int kc = 2 * c + half;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      float v = 0.f;
-      if (kc < CIN) {
-        const int idx = (a.wmode == 0) ? (col * CIN + kc) * 9 + t : (kc * 32 + col) * 9 + (8 - t);
-        v = a.w[idx];
-      }
-      wreg[c * 9 + t] = v;
-    }
+  for (int idx = threadIdx.x; idx < NS * 64; idx += 512) {
+    const int step = idx >> 6, l = idx & 63;
+    const int c = step / 9, t = step - 9 * c;
+    const int kc = 2 * c + (l >> 5), row = l & 31;
+    float v = 0.f;
+    if (kc < CIN) v = a.w[(a.wmode == 0) ? (row * CIN + kc) * 9 + t : (kc * 32 + row) * 9 + (8 - t)];
+    wl[idx] = v;
   }
+  __syncthreads();
+
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
-  const long total = (long)a.nb * P;
-  const long ntiles = (total + 31) >> 5;
+  const int total = a.nb * P;
+  const int ntiles = (total + 31) >> 5;
+  // contiguous run of tiles per workgroup, waves interleaved inside the run
+  const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+  const int t_beg = blockIdx.x * per;
+  const int t_end = min(ntiles, t_beg + per);
+  const float* wlane = wl + lane;
 
   // per-lane byte offset of a tile's pixel (clamped for the ragged last tile)
-  auto tile_voff = [&](long tile) {
-    long p = tile * 32 + col;
+  auto tile_voff = [&](int tile) {
+    int p = tile * 32 + col;
     if (p >= total) p = total - 1;
-    const int b = (int)(p / P);
-    const int rem = (int)(p - (long)b * P);
+    const int b = p / P;
+    const int rem = p - b * P;
     const int oy = rem / HOUT;
     const int ox = rem - oy * HOUT;
     return (((b * CIN + half) * HIN + oy * STRIDE) * HIN + ox * STRIDE) * 4;
   };
+  // the 9 taps of channel pair c (c may be a runtime value: it only moves the scalar offset)
   auto load_group = [&](float (&dst)[9], int voff, int c) {
+    const int cbase = c * (2 * HIN * HIN * 4);
+    // one 12-byte load per kernel row: the three kx taps of a lane are adjacent in memory
+    // (3x fewer vector-memory instructions than per-tap dword loads; the TA was the limiter)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int soff = ((2 * c) * HIN * HIN + (t / 3) * HIN + (t % 3)) * 4;
-      dst[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
+    for (int ky = 0; ky < 3; ++ky) {
+      const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, cbase + ky * HIN * 4, 0);
+      // (elements are copied to scalars first: __builtin_bit_cast on a vector-element lvalue
+      //  reads element 0 for every index with this clang)
+      const unsigned e0 = v[0], e1 = v[1], e2 = v[2];
+      dst[ky * 3 + 0] = __uint_as_float(e0);
+      dst[ky * 3 + 1] = __uint_as_float(e1);
+      dst[ky * 3 + 2] = __uint_as_float(e2);
     }
   };
+  auto mfma_group = [&](f32x16& acc, const float (&xv)[9], int c) {
+    const float* wp = wlane + c * (9 * 64);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wp[t * 64], xv[t], acc, 0, 0, 0);
+  };
 
-  // software pipeline: the 9 taps of channel pair c+1 (or of the next tile's pair 0) are in
-  // flight while the 9 MFMAs of pair c issue (9 x 64 cycles of cover for an L2 round trip).
-  float cur[9], nxt[9];
-  long tile = wave;
+  // software pipeline over channel pairs: the 9 taps of the next pair (or of the next tile's first pair)
+  // are in flight while the 9 MFMAs of the current pair issue; the other waves of the SIMD fill the rest.
+  float xa[9], xb[9];
+  int tile = t_beg + wid;
   int voff = 0;
-  if (tile < ntiles) {
+  if (tile < t_end) {
     voff = tile_voff(tile);
-    load_group(cur, voff, 0);
+    load_group(xa, voff, 0);
   }
-  for (; tile < ntiles; tile += nwaves) {
-    const long ntile = tile + nwaves < ntiles ? tile + nwaves : tile;   // last: harmless re-load
-    const int nvoff = tile_voff(ntile);
+  for (; tile < t_end; tile += 8) {
+    const int nvoff = tile_voff(tile + 8 < t_end ? tile + 8 : tile);   // last tile: harmless re-load
 
     // accumulator row (cout) of register r: (r&3) + 8*(r>>2) + 4*half; C-in = bias
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = a.bias ? a.bias[(r & 3) + 8 * (r >> 2) + 4 * half] : 0.f;
 
+    if constexpr (CP % 2 == 0) {
+#pragma unroll 1
+      for (int c = 0; c < CP; c += 2) {
+        load_group(xb, voff, c + 1);
+        mfma_group(acc, xa, c);
+        if (c + 2 < CP) load_group(xa, voff, c + 2);
+        else load_group(xa, nvoff, 0);
+        mfma_group(acc, xb, c + 1);
+      }
+    } else {
+#pragma unroll 1
+      for (int c = 0; c + 1 < CP; c += 2) {
+        load_group(xb, voff, c + 1);
+        mfma_group(acc, xa, c);
+        load_group(xa, voff, c + 2);
+        mfma_group(acc, xb, c + 1);
+      }
+      load_group(xb, nvoff, 0);
+      mfma_group(acc, xa, CP - 1);
 #pragma unroll
-    for (int c = 0; c < CP; ++c) {
-      if (c + 1 < CP) load_group(nxt, voff, c + 1);
-      else load_group(nxt, nvoff, 0);
-#pragma unroll
-      for (int t = 0; t < 9; ++t)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[c * 9 + t], cur[t], acc, 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < 9; ++t) cur[t] = nxt[t];
+      for (int t = 0; t < 9; ++t) xa[t] = xb[t];
     }
 
-    const long p = tile * 32 + col;
-    if (p < total) {
-      const int b = (int)(p / P);
-      const int rem = (int)(p - (long)b * P);
-      const int oy = rem / HOUT;
-      const int ox = rem - oy * HOUT;
+    int p = tile * 32 + col;
+    const bool valid = p < total;
+    const int b = p / P;
+    const int rem = p - b * P;
+    const int oy = rem / HOUT;
+    const int ox = rem - oy * HOUT;
+    voff = nvoff;
+    if (valid) {
       float* yo = a.y + a.y_off + (long)b * a.y_bs + (long)oy * a.y_rs + ox;
-      const float* mk = a.mask ? a.mask + ((long)b * 32) * P + rem : nullptr;
+      float mv[16];
+      if (a.mask) {       // all 16 mask loads in flight together
+        const float* mk = a.mask + ((long)b * 32) * P + rem;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mv[r] = mk[(long)((r & 3) + 8 * (r >> 2) + 4 * half) * P];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mv[r] = 1.f;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
         float v = acc[r];
         if (a.relu) v = v > 0.f ? v : 0.f;
-        if (mk) v = (mk[(long)co * P] > 0.f) ? v : 0.f;
+        v = mv[r] > 0.f ? v : 0.f;
         yo[(long)co * a.y_cs] = v;
       }
     }
-    voff = nvoff;
   }
 }
 
@@ -141,7 +182,7 @@ struct WgradArgs {
   const float* x;     // layer input  [NB][CIN][HIN][HIN]
   const float* dy;    // grad of the pre-activation, [NB][32][dy rows][dy cols] addressed with strides
   long dy_bs, dy_cs, dy_rs, dy_off;
-  float* part;        // [nblocks][NT*1024 + 32]
+  float* part;        // [nblocks][PART]
   int nb;
 };
 
@@ -157,12 +198,14 @@ struct WgradGeom {
   static constexpr int XS = 3 * CIN * XP;                   // floats of X per wave
   static constexpr int WAVE_LDS = XS + 32 * DP;             // floats per wave
   static constexpr int PART = NT * 1024 + 64;               // floats per partial record
+  static constexpr int XSEG = (HIN + 63) / 64;              // 64-lane pieces per input row
+  static constexpr int NXR = 3 * CIN * XSEG;                // staging registers for X
 };
 
 template <int CIN, int HIN, int STRIDE>
 __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(WgradArgs a) {
   using G = WgradGeom<CIN, HIN, STRIDE>;
-  constexpr int HOUT = G::HOUT, KS = G::KS, XP = G::XP, DP = G::DP, NT = G::NT;
+  constexpr int HOUT = G::HOUT, KS = G::KS, XP = G::XP, DP = G::DP, NT = G::NT, XSEG = G::XSEG;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
@@ -197,25 +240,43 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(WgradArgs a) {
   const long gw = (long)blockIdx.x * 4 + wid;
   const long u0 = units * gw / nw, u1 = units * (gw + 1) / nw;
 
-  for (long u = u0; u < u1; ++u) {
+  // ---- register staging: one (ky,ci) input row piece / one dY row per load instruction
+  float rx[G::NXR], rd[32];
+  auto issue_loads = [&](long u) {
     const int b = (int)(u / HOUT);
     const int oy = (int)(u - (long)b * HOUT);
-    // ---- stage: 3 input rows x CIN channels, one dY row x 32 channels (coalesced along x)
     const float* xg = a.x + ((long)b * CIN * HIN + (long)oy * STRIDE) * HIN;
-    for (int i = lane; i < 3 * CIN * HIN; i += 64) {
-      const int ky = i / (CIN * HIN);
-      const int r2 = i - ky * (CIN * HIN);
-      const int ci = r2 / HIN;
-      const int xx = r2 - ci * HIN;
-      xs[(ky * CIN + ci) * XP + xx] = xg[((long)ci * HIN + ky) * HIN + xx];
-    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+        for (int sg = 0; sg < XSEG; ++sg) {
+          const int xx = sg * 64 + lane;
+          rx[(ky * CIN + ci) * XSEG + sg] = xx < HIN ? xg[((long)ci * HIN + ky) * HIN + xx] : 0.f;
+        }
     const float* dg = a.dy + a.dy_off + (long)b * a.dy_bs + (long)oy * a.dy_rs;
-    for (int i = lane; i < 32 * HOUT; i += 64) {
-      const int co = i / HOUT;
-      const int xx = i - co * HOUT;
-      ds[co * DP + xx] = dg[(long)co * a.dy_cs + xx];
-    }
+#pragma unroll
+    for (int co = 0; co < 32; ++co) rd[co] = lane < HOUT ? dg[(long)co * a.dy_cs + lane] : 0.f;
+  };
+  auto write_lds = [&]() {
+#pragma unroll
+    for (int r = 0; r < 3 * CIN; ++r)
+#pragma unroll
+      for (int sg = 0; sg < XSEG; ++sg) {
+        const int xx = sg * 64 + lane;
+        if (xx < HIN) xs[r * XP + xx] = rx[r * XSEG + sg];
+      }
+#pragma unroll
+    for (int co = 0; co < 32; ++co)
+      if (lane < HOUT) ds[co * DP + lane] = rd[co];
+  };
+
+  if (u0 < u1) issue_loads(u0);
+  for (long u = u0; u < u1; ++u) {
     // (single wave: LDS operations of one wave complete in order, no barrier needed)
+    write_lds();
+    if (u + 1 < u1) issue_loads(u + 1);   // in flight under the MFMA loop below
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const float av = ds[abase + 2 * s];
@@ -232,7 +293,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(WgradArgs a) {
 
   // ---- reduce the 4 waves of the block through LDS, one partial record per block
   __syncthreads();
-  float* red = smem;   // [4][NT*1024 + 64]  (fits: checked on the host)
+  float* red = smem;   // [4][PART]  (fits: checked on the host)
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -244,52 +305,50 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(WgradArgs a) {
     out[i] = (red[i] + red[G::PART + i]) + (red[2 * G::PART + i] + red[3 * G::PART + i]);
 }
 
-// sums the per-block partial records in a fixed order and scatters to the canonical layouts
+// Sums the per-block partial records in a fixed order and scatters to the canonical layouts.
+// Block = 64 record elements x 16 groups of partials (1024 threads).
 template <int CIN, bool SMALL>
-__global__ void conv3x3_wgrad_reduce_kernel(const float* part, int nblocks, float* dw, float* db) {
+__global__ __launch_bounds__(1024) void conv3x3_wgrad_reduce_kernel(const float* part, int nblocks, float* dw,
+                                                                    float* db) {
   constexpr int NT = SMALL ? 3 : 9;
   constexpr int PART = NT * 1024 + 64;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= PART) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int k = 0;
-  for (; k + 3 < nblocks; k += 4) {
-    s0 += part[(long)(k + 0) * PART + i];
-    s1 += part[(long)(k + 1) * PART + i];
-    s2 += part[(long)(k + 2) * PART + i];
-    s3 += part[(long)(k + 3) * PART + i];
-  }
-  for (; k < nblocks; ++k) s0 += part[(long)k * PART + i];
-  const float s = (s0 + s1) + (s2 + s3);
+  __shared__ float sm[16][64];
+  const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + e;        // PART is a multiple of 64
+  float s = 0.f;
+  for (int k = grp; k < nblocks; k += 16) s += part[(long)k * PART + i];
+  sm[grp][e] = s;
+  __syncthreads();
+  if (grp != 0) return;
+  float tot = 0.f;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) tot += sm[g][e];
   if (i < NT * 1024) {
     const int t = i >> 10, r = (i >> 6) & 15, lane = i & 63;
     const int col = lane & 31, half = lane >> 5;
     const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
     if (SMALL) {
-      if (col < CIN * 3) dw[(co * CIN + col / 3) * 9 + t * 3 + col % 3] = s;
+      if (col < CIN * 3) dw[(co * CIN + col / 3) * 9 + t * 3 + col % 3] = tot;
     } else {
-      if (col < CIN) dw[(co * CIN + col) * 9 + t] = s;
+      if (col < CIN) dw[(co * CIN + col) * 9 + t] = tot;
     }
   } else {
     // bias partials: lane (cout, half); the two halves hold even / odd pixels
-    const int lane = i - NT * 1024;
-    if (lane < 32) {
-      float o = 0.f;
-      for (int k2 = 0; k2 < nblocks; ++k2) o += part[(long)k2 * PART + NT * 1024 + lane + 32];
-      db[lane] = s + o;
-    }
+    const float other = __shfl_xor(tot, 32);
+    if (e < 32) db[e] = tot + other;
   }
 }
 
 template <int CIN, int HIN, int STRIDE>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
   constexpr int HOUT = (HIN - 3) / STRIDE + 1;
+  constexpr int BLK = 2;
   const long ntiles = ((long)a.nb * HOUT * HOUT + 31) / 32;
-  long blocks = (ntiles + 3) / 4;
-  const long cap = 2L * drq_num_cus();
+  long blocks = (ntiles + 7) / 8;
+  const long cap = (long)BLK * drq_num_cus();
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((conv3x3_kernel<CIN, HIN, STRIDE>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((conv3x3_kernel<CIN, HIN, STRIDE, BLK>), dim3((unsigned)blocks), dim3(512), 0, st, a);
   DRQ_LAUNCH_CHECK();
   return DRQ_OK;
 }
@@ -299,6 +358,7 @@ int launch_wgrad(const WgradArgs& a0, float* dw, float* db, float* ws, size_t ws
   using G = WgradGeom<CIN, HIN, STRIDE>;
   static_assert(4 * G::WAVE_LDS * 4 <= 160 * 1024, "LDS tile too large");
   static_assert(4 * G::PART * 4 <= 160 * 1024, "reduction tile too large");
+  static_assert(G::PART % 64 == 0, "record size");
   constexpr int lds_floats = (4 * G::WAVE_LDS > 4 * G::PART) ? 4 * G::WAVE_LDS : 4 * G::PART;
   const long units = (long)a0.nb * G::HOUT;
   long blocks = drq_num_cus();
@@ -317,7 +377,7 @@ int launch_wgrad(const WgradArgs& a0, float* dw, float* db, float* ws, size_t ws
   hipLaunchKernelGGL((conv3x3_wgrad_kernel<CIN, HIN, STRIDE>), dim3((unsigned)blocks), dim3(256),
                      lds_floats * 4, st, a);
   DRQ_LAUNCH_CHECK();
-  hipLaunchKernelGGL((conv3x3_wgrad_reduce_kernel<CIN, G::SMALL>), dim3((G::PART + 255) / 256), dim3(256), 0, st,
+  hipLaunchKernelGGL((conv3x3_wgrad_reduce_kernel<CIN, G::SMALL>), dim3(G::PART / 64), dim3(1024), 0, st,
                      (const float*)ws, (int)blocks, dw, db);
   DRQ_LAUNCH_CHECK();
   return DRQ_OK;
@@ -335,7 +395,7 @@ int drq_conv3x3_fwd(const float* x, const float* w, const float* bias, float* y,
                     int stride, int relu, long y_bs, long y_cs, long y_rs, long y_off, hipStream_t st) {
   if (!x || !w || !y || nb <= 0) return DRQ_EARG;
   const size_t xb = (size_t)nb * cin * hin * hin * 4;
-  if (xb >= (1ull << 32)) return DRQ_EARG;
+  if (xb >= (1ull << 31)) return DRQ_EARG;
   ConvArgs a{x, w, bias, nullptr, y, y_bs, y_cs, y_rs, y_off, (unsigned)xb, nb, relu, 0};
   if (cin == 9 && hin == 84 && stride == 2) return launch_conv<9, 84, 2>(a, st);
   if (cin == 32 && stride == 1) {
@@ -353,7 +413,7 @@ int drq_conv3x3_dgrad(const float* dy_pad, const float* w, const float* mask, fl
   if (!dy_pad || !w || !dx || nb <= 0) return DRQ_EARG;
   const int hp = hout + 4;
   const size_t xb = (size_t)nb * 32 * hp * hp * 4;
-  if (xb >= (1ull << 32)) return DRQ_EARG;
+  if (xb >= (1ull << 31)) return DRQ_EARG;
   ConvArgs a{dy_pad, w, nullptr, mask, dx, dx_bs, dx_cs, dx_rs, dx_off, (unsigned)xb, nb, 0, 1};
   if (hp == 39) return launch_conv<32, 39, 1>(a, st);
   if (hp == 41) return launch_conv<32, 41, 1>(a, st);

@@ -17,6 +17,10 @@ template <typename T>
 __global__ void aug_kernel(const T* __restrict__ obs, const float* __restrict__ shift,
                            const float* __restrict__ base, float* __restrict__ out, int n, int c, int h,
                            int pad, int fuse_norm) {
+  // one rounding per operation, in the order of the CPU restatement (oracle/drq_oracle.py
+  // random_shifts_aug): the tap weights are differences of nearly equal numbers, so a fused
+  // multiply-add anywhere in the coordinate chain changes them by O(1) relative.
+#pragma clang fp contract(off)
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int hw = h * h;
   if (idx >= (long)n * hw) return;
@@ -43,10 +47,10 @@ __global__ void aug_kernel(const T* __restrict__ obs, const float* __restrict__ 
   for (int ch = 0; ch < c; ++ch) {
     const T* s = src + (long)ch * hw;
     float v = 0.f;
-    if (okx0 && oky0) v = __fmaf_rn((float)s[sy0 * h + sx0], w00, v);
-    if (okx1 && oky0) v = __fmaf_rn((float)s[sy0 * h + sx1], w01, v);
-    if (okx0 && oky1) v = __fmaf_rn((float)s[sy1 * h + sx0], w10, v);
-    if (okx1 && oky1) v = __fmaf_rn((float)s[sy1 * h + sx1], w11, v);
+    if (okx0 && oky0) v = __fadd_rn(v, __fmul_rn((float)s[sy0 * h + sx0], w00));
+    if (okx1 && oky0) v = __fadd_rn(v, __fmul_rn((float)s[sy0 * h + sx1], w01));
+    if (okx0 && oky1) v = __fadd_rn(v, __fmul_rn((float)s[sy1 * h + sx0], w10));
+    if (okx1 && oky1) v = __fadd_rn(v, __fmul_rn((float)s[sy1 * h + sx1], w11));
     if (fuse_norm) v = v / 255.0f - 0.5f;
     dst[(long)ch * hw] = v;
   }
@@ -325,14 +329,17 @@ __global__ void actor_dmu_kernel(const float* dha1, const float* dha2, long ld, 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long n, float neg_step_size, float sqrt_bc2, float gscale,
                             float* __restrict__ tgt, float tau, float one_minus_tau) {
+  // one rounding per operation, in torch's order (oracle/drq_oracle.py:adam_step); sqrtf and / are the
+  // IEEE-correct forms (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt); __fsqrt_rn is NOT.
+#pragma clang fp contract(off)
   const float w1 = (float)(1.0 - 0.9), b2 = 0.999f, w2 = (float)(1.0 - 0.999), eps = 1e-8f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float gi = g[i];
     if (gscale != 1.0f) gi *= gscale;
     const float mi = __fmaf_rn(w1, __fsub_rn(gi, m[i]), m[i]);
     const float vi = __fmaf_rn(__fmul_rn(gi, w2), gi, __fmul_rn(v[i], b2));
-    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), sqrt_bc2), eps);
-    const float pi = __fmaf_rn(neg_step_size, __fdiv_rn(mi, denom), p[i]);
+    const float denom = __fadd_rn(__fdiv_rn(sqrtf(vi), sqrt_bc2), eps);
+    const float pi = __fadd_rn(p[i], __fdiv_rn(__fmul_rn(neg_step_size, mi), denom));
     m[i] = mi;
     v[i] = vi;
     p[i] = pi;
@@ -342,6 +349,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 
 __global__ void ema_kernel(const float* __restrict__ p, float* __restrict__ t, long n, float tau,
                            float one_minus_tau) {
+#pragma clang fp contract(off)
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     t[i] = __fadd_rn(__fmul_rn(tau, p[i]), __fmul_rn(one_minus_tau, t[i]));
 }

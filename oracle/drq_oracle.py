@@ -26,6 +26,8 @@ Reference citations (``/root/reference``):
 """
 import math
 import re
+
+import numpy as np
 from collections import OrderedDict
 
 import torch
@@ -133,9 +135,9 @@ def aug_integer_crop(x, shift_xy, pad=4):
 # --------------------------------------------------------------------------
 # networks (functional): drqv2.py:48-121
 # --------------------------------------------------------------------------
-def encoder_forward(p, obs, return_acts=False):
-    """p: dict with ENC_KEYS.  obs: [B,C,84,84] float (0..255 scale)."""
-    x = obs / 255.0 - 0.5                                        # drqv2.py:64
+def encoder_forward(p, obs, return_acts=False, normalized=False):
+    """p: dict with ENC_KEYS.  obs: [B,C,84,84] float (0..255 scale; already /255-0.5 if normalized)."""
+    x = obs if normalized else obs / 255.0 - 0.5                 # drqv2.py:64
     acts = [x]
     for li, i in enumerate((0, 2, 4, 6)):
         x = F.conv2d(x, p[f"convnet.{i}.weight"], p[f"convnet.{i}.bias"],
@@ -212,7 +214,7 @@ def adam_step(p, g, m, v, t, lr):
     The rounding sequence below is the one torch's CPU kernels were measured to
     follow bit-for-bit (tests/golden/elementwise.npz):
       m = fma(1-b1, g-m, m);  v = fma(fl((1-b2)*g), g, fl(b2*v));
-      denom = fl(fl(sqrt(v)/sqrt(bc2)) + eps);  p = fma(-lr/bc1, fl(m/denom), p)."""
+      denom = fl(fl(sqrt(v)/sqrt(bc2)) + eps);  p = fl(p + fl(fl(-lr/bc1 * m) / denom))."""
     dt = p.dtype
     c = lambda x: torch.tensor(x, dtype=dt)
     m.copy_(_fma(c(1 - ADAM_B1).expand_as(g), g - m, m))
@@ -220,8 +222,11 @@ def adam_step(p, g, m, v, t, lr):
     bc1 = 1 - ADAM_B1 ** t
     bc2 = 1 - ADAM_B2 ** t
     step_size = lr / bc1
-    denom = v.sqrt() / c(bc2 ** 0.5) + c(ADAM_EPS)
-    p.copy_(_fma(c(-step_size).expand_as(p), m / denom, p))
+    # IEEE-correct square root: torch's vectorised CPU sqrt is only ~1 ulp and differs between CPUs
+    # (0.7 % of fp32 values on the build container), numpy's is the hardware sqrtps
+    sq = torch.from_numpy(np.sqrt(v.detach().numpy())) if dt == torch.float32 else v.sqrt()
+    denom = sq / c(bc2 ** 0.5) + c(ADAM_EPS)
+    p.add_((m * c(-step_size)) / denom)
 
 
 def polyak(p, t, tau):
@@ -307,7 +312,7 @@ class OracleAgent:
 
     # -- the hot path ----------------------------------------------------
     def update(self, batch, step, shifts_obs, shifts_next, noise_critic, noise_actor,
-               aug_base=None, aug_override=None, keep=False):
+               aug_base=None, aug_override=None, enc_in_override=None, keep=False):
         """batch = (obs u8 [B,C,84,84], action [B,A], reward [B,1], discount [B,1],
         next_obs u8).  Returns the 8-key metrics dict of drqv2.py (python floats)."""
         if step % self.update_every_steps != 0:
@@ -321,7 +326,10 @@ class OracleAgent:
         B = obs_u8.shape[0]
         metrics = {}
 
-        if aug_override is not None:
+        normalized = enc_in_override is not None
+        if normalized:          # the encoder inputs (after aug and /255-0.5) are injected
+            obs_a, next_a = (t.to(dt) for t in enc_in_override)
+        elif aug_override is not None:
             obs_a, next_a = (t.to(dt) for t in aug_override)
         else:
             base = None if aug_base is None else aug_base.to(dt)
@@ -330,9 +338,9 @@ class OracleAgent:
 
         req = lambda d: OrderedDict((k, v.detach().requires_grad_(True)) for k, v in d.items())
         enc, critic = req(self.enc), req(self.critic)
-        feat, acts = encoder_forward(enc, obs_a, return_acts=True)              # :244
+        feat, acts = encoder_forward(enc, obs_a, return_acts=True, normalized=normalized)   # :244
         with torch.no_grad():
-            feat_next = encoder_forward(self.enc, next_a)                       # :245-246
+            feat_next = encoder_forward(self.enc, next_a, normalized=normalized)            # :245-246
         metrics["batch_reward"] = reward.mean().item()
 
         # ---- critic step: drqv2.py:177-204

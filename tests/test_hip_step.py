@@ -74,10 +74,15 @@ def test_update_matches_oracle(name, golden_steps):
     for u in range(cfg["updates"]):
         step = cfg["step0"] + 2 * u
         m, batch, (sh_o, sh_n, n_c, n_a) = run_hip(ag, cfg, u)
-        # both oracles get the same fp32 augmented frames (the aug op itself is pinned in test_hip_ops)
-        ov = (O.random_shifts_aug(batch[0].float(), sh_o, 4, base), O.random_shifts_aug(batch[4].float(), sh_n, 4, base))
-        m32 = o32.update(batch, step, sh_o, sh_n, n_c, n_a, aug_override=ov, keep=True)
-        m64 = o64.update(batch, step, sh_o, sh_n, n_c, n_a, aug_override=ov, keep=True)
+        # both oracles get the encoder inputs the HIP step produced (aug + /255-0.5; that op is pinned
+        # on its own in test_hip_ops): everything downstream then sees identical upstream tensors
+        Bq = cfg["B"]
+        xin = ag._engine.ws_view("AUG", Bq, (2 * Bq, cfg["C"], 84, 84)).cpu()
+        ora_in = O.random_shifts_aug(batch[0].float(), sh_o, 4, base) / 255.0 - 0.5
+        assert (xin[:Bq] - ora_in).abs().max().item() <= 1e-6
+        ov = (xin[:Bq], xin[Bq:])
+        m32 = o32.update(batch, step, sh_o, sh_n, n_c, n_a, enc_in_override=ov, keep=True)
+        m64 = o64.update(batch, step, sh_o, sh_n, n_c, n_a, enc_in_override=ov, keep=True)
         assert list(m.keys()) == list(m64.keys())
         # later updates inherit the sign-SGD amplification of Adam at t=1 (SURVEY finding 3)
         tol = 1e-5 if u == 0 else 3e-3
