@@ -23,6 +23,7 @@
 // registers.  Partials: 4 waves -> LDS -> one record per workgroup -> fixed-order reduction kernel
 // (deterministic, no float atomics).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -33,20 +34,21 @@ struct ConvArgs {
   const float* mask;   // [NB][32][HOUT][HOUT] or null : out *= (mask > 0)
   float* y;
   long y_bs, y_cs, y_rs, y_off;   // output strides (elements)
-  unsigned x_bytes;
+  unsigned x_bytes, y_bytes, mask_bytes;
   int nb;
   int relu;
   int wmode;           // 0 forward gather, 1 dgrad gather (transposed + flipped)
 };
 
 // BLK = workgroups per CU the kernel is tuned for (8 waves each): 2 -> 4 waves/SIMD (<=128 VGPR)
-template <int CIN, int HIN, int STRIDE, int BLK>
+template <int CIN, int HIN, int STRIDE, int BLK, int TPW>
 __global__ __launch_bounds__(512, 2 * BLK) void conv3x3_kernel(ConvArgs a) {
   constexpr int CP = (CIN + 1) / 2;
   constexpr int NS = CP * 9;                 // MFMA steps per tile
   constexpr int HOUT = (HIN - 3) / STRIDE + 1;
   constexpr int P = HOUT * HOUT;
   __shared__ float wl[NS * 64];              // A operand, [step][lane]
+  __shared__ float bl[32];                   // bias
 
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
@@ -61,10 +63,16 @@ __global__ __launch_bounds__(512, 2 * BLK) void conv3x3_kernel(ConvArgs a) {
     if (kc < CIN) v = a.w[(a.wmode == 0) ? (row * CIN + kc) * 9 + t : (kc * 32 + row) * 9 + (8 - t)];
     wl[idx] = v;
   }
+  if (threadIdx.x < 32) bl[threadIdx.x] = a.bias ? a.bias[threadIdx.x] : 0.f;
   __syncthreads();
 
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  // output / mask through buffer descriptors too: one 32-bit per-lane offset + scalar channel offsets
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, a.y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t mrsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.mask, 0, a.mask ? a.mask_bytes : 0, 0x00020000);
+  const int ycs4 = (int)a.y_cs * 4;
   const int total = a.nb * P;
   const int ntiles = (total + 31) >> 5;
   // contiguous run of tiles per workgroup, waves interleaved inside the run
@@ -99,78 +107,103 @@ __global__ __launch_bounds__(512, 2 * BLK) void conv3x3_kernel(ConvArgs a) {
       dst[ky * 3 + 2] = __uint_as_float(e2);
     }
   };
-  auto mfma_group = [&](f32x16& acc, const float (&xv)[9], int c) {
+  // TPW pixel tiles per wave iteration: TPW independent accumulator chains share one A (weight) read,
+  // so a wave always has an MFMA that does not depend on the one in flight.
+  auto mfma_group = [&](f32x16 (&acc)[TPW], const float (&xv)[TPW][9], int c) {
     const float* wp = wlane + c * (9 * 64);
 #pragma unroll
-    for (int t = 0; t < 9; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wp[t * 64], xv[t], acc, 0, 0, 0);
+    for (int t = 0; t < 9; ++t) {
+      const float wv = wp[t * 64];
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, xv[j][t], acc[j], 0, 0, 0);
+    }
+  };
+  auto store_tile = [&](int tile, const f32x16& acc) {
+    const int p = tile * 32 + col;
+    if (tile >= t_end || p >= total) return;
+    const int b = p / P;
+    const int rem = p - b * P;
+    const int oy = rem / HOUT;
+    const int ox = rem - oy * HOUT;
+    // register r holds cout = (r&3) + 8*(r>>2) + 4*half: the 4*half part rides in the lane offset
+    const int yoff = ((int)a.y_off + b * (int)a.y_bs + oy * (int)a.y_rs + ox) * 4 + half * 4 * ycs4;
+    const int moff = ((b * 32 + 4 * half) * P + rem) * 4;
+    float mv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)   // zero-sized descriptor (no mask): every load returns 0 and is ignored
+      mv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(mrsrc, moff, ((r & 3) + 8 * (r >> 2)) * P * 4, 0));
+    const bool use_mask = a.mask != nullptr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = acc[r];
+      if (a.relu) v = v > 0.f ? v : 0.f;
+      if (use_mask) v = mv[r] > 0.f ? v : 0.f;
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrsrc, yoff, ((r & 3) + 8 * (r >> 2)) * ycs4, 0);
+    }
   };
 
-  // software pipeline over channel pairs: the 9 taps of the next pair (or of the next tile's first pair)
-  // are in flight while the 9 MFMAs of the current pair issue; the other waves of the SIMD fill the rest.
-  float xa[9], xb[9];
-  int tile = t_beg + wid;
-  int voff = 0;
+  // software pipeline over channel pairs: the taps of the next pair (or of the next tiles' first pair)
+  // are in flight while the MFMAs of the current pair issue; the other waves of the SIMD fill the rest.
+  float xa[TPW][9], xb[TPW][9];
+  int voff[TPW], nvoff[TPW];
+  int tile = t_beg + wid * TPW;
+  auto clampt = [&](int t) { return t < t_end ? t : t_end - 1; };   // ragged end: harmless re-load
   if (tile < t_end) {
-    voff = tile_voff(tile);
-    load_group(xa, voff, 0);
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+      voff[j] = tile_voff(clampt(tile + j));
+      load_group(xa[j], voff[j], 0);
+    }
   }
-  for (; tile < t_end; tile += 8) {
-    const int nvoff = tile_voff(tile + 8 < t_end ? tile + 8 : tile);   // last tile: harmless re-load
+  for (; tile < t_end; tile += 8 * TPW) {
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) nvoff[j] = tile_voff(clampt(tile + 8 * TPW + j));
 
     // accumulator row (cout) of register r: (r&3) + 8*(r>>2) + 4*half; C-in = bias
-    f32x16 acc;
+    f32x16 acc[TPW];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = a.bias ? a.bias[(r & 3) + 8 * (r >> 2) + 4 * half] : 0.f;
+    for (int r = 0; r < 16; ++r) {
+      const float bv = bl[(r & 3) + 8 * (r >> 2) + 4 * half];
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) acc[j][r] = bv;
+    }
 
     if constexpr (CP % 2 == 0) {
 #pragma unroll 1
       for (int c = 0; c < CP; c += 2) {
-        load_group(xb, voff, c + 1);
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) load_group(xb[j], voff[j], c + 1);
         mfma_group(acc, xa, c);
-        if (c + 2 < CP) load_group(xa, voff, c + 2);
-        else load_group(xa, nvoff, 0);
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+          if (c + 2 < CP) load_group(xa[j], voff[j], c + 2);
+          else load_group(xa[j], nvoff[j], 0);
+        }
         mfma_group(acc, xb, c + 1);
       }
     } else {
 #pragma unroll 1
       for (int c = 0; c + 1 < CP; c += 2) {
-        load_group(xb, voff, c + 1);
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) load_group(xb[j], voff[j], c + 1);
         mfma_group(acc, xa, c);
-        load_group(xa, voff, c + 2);
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) load_group(xa[j], voff[j], c + 2);
         mfma_group(acc, xb, c + 1);
       }
-      load_group(xb, nvoff, 0);
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) load_group(xb[j], nvoff[j], 0);
       mfma_group(acc, xa, CP - 1);
 #pragma unroll
-      for (int t = 0; t < 9; ++t) xa[t] = xb[t];
+      for (int j = 0; j < TPW; ++j)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) xa[j][t] = xb[j][t];
     }
 
-    int p = tile * 32 + col;
-    const bool valid = p < total;
-    const int b = p / P;
-    const int rem = p - b * P;
-    const int oy = rem / HOUT;
-    const int ox = rem - oy * HOUT;
-    voff = nvoff;
-    if (valid) {
-      float* yo = a.y + a.y_off + (long)b * a.y_bs + (long)oy * a.y_rs + ox;
-      float mv[16];
-      if (a.mask) {       // all 16 mask loads in flight together
-        const float* mk = a.mask + ((long)b * 32) * P + rem;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mv[r] = mk[(long)((r & 3) + 8 * (r >> 2) + 4 * half) * P];
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mv[r] = 1.f;
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
-        float v = acc[r];
-        if (a.relu) v = v > 0.f ? v : 0.f;
-        v = mv[r] > 0.f ? v : 0.f;
-        yo[(long)co * a.y_cs] = v;
-      }
+    for (int j = 0; j < TPW; ++j) {
+      store_tile(tile + j, acc[j]);
+      voff[j] = nvoff[j];
     }
   }
 }
@@ -339,18 +372,39 @@ __global__ __launch_bounds__(1024) void conv3x3_wgrad_reduce_kernel(const float*
   }
 }
 
-template <int CIN, int HIN, int STRIDE>
-int launch_conv(const ConvArgs& a, hipStream_t st) {
+template <int CIN, int HIN, int STRIDE, int BLK, int TPW>
+int launch_conv_v(const ConvArgs& a, hipStream_t st) {
   constexpr int HOUT = (HIN - 3) / STRIDE + 1;
-  constexpr int BLK = 2;
   const long ntiles = ((long)a.nb * HOUT * HOUT + 31) / 32;
-  long blocks = (ntiles + 7) / 8;
+  long blocks = (ntiles + 8 * TPW - 1) / (8 * TPW);
   const long cap = (long)BLK * drq_num_cus();
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((conv3x3_kernel<CIN, HIN, STRIDE, BLK>), dim3((unsigned)blocks), dim3(512), 0, st, a);
+  hipLaunchKernelGGL((conv3x3_kernel<CIN, HIN, STRIDE, BLK, TPW>), dim3((unsigned)blocks), dim3(512), 0, st, a);
   DRQ_LAUNCH_CHECK();
   return DRQ_OK;
+}
+
+// DRQ_CONV_VARIANT (development knob, read once): workgroups per CU x accumulator chains per wave
+inline int conv_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("DRQ_CONV_VARIANT");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
+template <int CIN, int HIN, int STRIDE>
+int launch_conv(const ConvArgs& a, hipStream_t st) {
+  switch (conv_variant()) {
+    case 1: return launch_conv_v<CIN, HIN, STRIDE, 2, 2>(a, st);
+    case 2: return launch_conv_v<CIN, HIN, STRIDE, 1, 2>(a, st);
+    case 3: return launch_conv_v<CIN, HIN, STRIDE, 3, 1>(a, st);
+    case 4: return launch_conv_v<CIN, HIN, STRIDE, 1, 4>(a, st);
+    case 5: return launch_conv_v<CIN, HIN, STRIDE, 4, 1>(a, st);
+    default: return launch_conv_v<CIN, HIN, STRIDE, 2, 1>(a, st);
+  }
 }
 
 template <int CIN, int HIN, int STRIDE>
@@ -396,7 +450,9 @@ int drq_conv3x3_fwd(const float* x, const float* w, const float* bias, float* y,
   if (!x || !w || !y || nb <= 0) return DRQ_EARG;
   const size_t xb = (size_t)nb * cin * hin * hin * 4;
   if (xb >= (1ull << 31)) return DRQ_EARG;
-  ConvArgs a{x, w, bias, nullptr, y, y_bs, y_cs, y_rs, y_off, (unsigned)xb, nb, relu, 0};
+  const size_t yb = (size_t)nb * y_bs * 4;
+  if (yb >= (1ull << 31) || y_off < 0 || y_bs <= 0) return DRQ_EARG;
+  ConvArgs a{x, w, bias, nullptr, y, y_bs, y_cs, y_rs, y_off, (unsigned)xb, (unsigned)yb, 0u, nb, relu, 0};
   if (cin == 9 && hin == 84 && stride == 2) return launch_conv<9, 84, 2>(a, st);
   if (cin == 32 && stride == 1) {
     if (hin == 41) return launch_conv<32, 41, 1>(a, st);
@@ -414,7 +470,11 @@ int drq_conv3x3_dgrad(const float* dy_pad, const float* w, const float* mask, fl
   const int hp = hout + 4;
   const size_t xb = (size_t)nb * 32 * hp * hp * 4;
   if (xb >= (1ull << 31)) return DRQ_EARG;
-  ConvArgs a{dy_pad, w, nullptr, mask, dx, dx_bs, dx_cs, dx_rs, dx_off, (unsigned)xb, nb, 0, 1};
+  const size_t yb = (size_t)nb * dx_bs * 4;
+  const size_t mb = (size_t)nb * 32 * (hout + 2) * (hout + 2) * 4;
+  if (yb >= (1ull << 31) || dx_off < 0 || dx_bs <= 0) return DRQ_EARG;
+  ConvArgs a{dy_pad, w, nullptr, mask, dx, dx_bs, dx_cs, dx_rs, dx_off, (unsigned)xb, (unsigned)yb, (unsigned)mb,
+             nb, 0, 1};
   if (hp == 39) return launch_conv<32, 39, 1>(a, st);
   if (hp == 41) return launch_conv<32, 41, 1>(a, st);
   if (hp == 43) return launch_conv<32, 43, 1>(a, st);

@@ -44,15 +44,32 @@ __global__ void aug_kernel(const T* __restrict__ obs, const float* __restrict__ 
   const int sx0 = cl(x0), sx1 = cl(x0 + 1), sy0 = cl(y0), sy1 = cl(y0 + 1);
   const T* src = obs + (long)b * c * hw;
   float* dst = out + (long)b * c * hw + r;
-  for (int ch = 0; ch < c; ++ch) {
-    const T* s = src + (long)ch * hw;
+  const int o00 = sy0 * h + sx0, o01 = sy0 * h + sx1, o10 = sy1 * h + sx0, o11 = sy1 * h + sx1;
+  const bool k00 = okx0 && oky0, k01 = okx1 && oky0, k10 = okx0 && oky1, k11 = okx1 && oky1;
+  auto blend = [&](float t00, float t01, float t10, float t11) {
     float v = 0.f;
-    if (okx0 && oky0) v = __fadd_rn(v, __fmul_rn((float)s[sy0 * h + sx0], w00));
-    if (okx1 && oky0) v = __fadd_rn(v, __fmul_rn((float)s[sy0 * h + sx1], w01));
-    if (okx0 && oky1) v = __fadd_rn(v, __fmul_rn((float)s[sy1 * h + sx0], w10));
-    if (okx1 && oky1) v = __fadd_rn(v, __fmul_rn((float)s[sy1 * h + sx1], w11));
+    if (k00) v = __fadd_rn(v, __fmul_rn(t00, w00));
+    if (k01) v = __fadd_rn(v, __fmul_rn(t01, w01));
+    if (k10) v = __fadd_rn(v, __fmul_rn(t10, w10));
+    if (k11) v = __fadd_rn(v, __fmul_rn(t11, w11));
     if (fuse_norm) v = v / 255.0f - 0.5f;
-    dst[(long)ch * hw] = v;
+    return v;
+  };
+  if (c == 9) {          // frame_stack 3 (cfgs/config.yaml:7): all 36 tap loads in flight together
+    T t[9][4];
+#pragma unroll
+    for (int ch = 0; ch < 9; ++ch) {
+      const T* s = src + (long)ch * hw;
+      t[ch][0] = s[o00]; t[ch][1] = s[o01]; t[ch][2] = s[o10]; t[ch][3] = s[o11];
+    }
+#pragma unroll
+    for (int ch = 0; ch < 9; ++ch)
+      dst[(long)ch * hw] = blend((float)t[ch][0], (float)t[ch][1], (float)t[ch][2], (float)t[ch][3]);
+  } else {
+    for (int ch = 0; ch < c; ++ch) {
+      const T* s = src + (long)ch * hw;
+      dst[(long)ch * hw] = blend((float)s[o00], (float)s[o01], (float)s[o10], (float)s[o11]);
+    }
   }
 }
 
@@ -189,18 +206,31 @@ __global__ void ln_param_grad_kernel(const float* dln, const float* xhat, float*
 // ------------------------------------------------------------------------------------------------
 // column sums (bias gradients): out[batch][n] = sum_m dy[batch][m][n].  Block = 64 columns x 4 row groups.
 // ------------------------------------------------------------------------------------------------
-__global__ void colsum_kernel(const float* dy, long ld, long dy_bs, float* out, long out_bs, int M, int N) {
-  __shared__ float s[4][64];
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* dy, long ld, long dy_bs, float* out, long out_bs,
+                                                      int M, int N) {
+  __shared__ float s[16][64];
   const int batch = blockIdx.y;
-  const int n = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int rg = threadIdx.x >> 6;
+  const int c = threadIdx.x & 63;
+  const int n = blockIdx.x * 64 + c;
+  const int rg = threadIdx.x >> 6;          // 16 row groups
   const float* p = dy + batch * dy_bs;
-  float acc = 0.f;
-  if (n < N)
-    for (int m = rg; m < M; m += 4) acc += p[(long)m * ld + n];
-  s[rg][threadIdx.x & 63] = acc;
+  float a0 = 0.f, a1 = 0.f;
+  if (n < N) {
+    int m = rg;
+    for (; m + 16 < M; m += 32) {           // two independent chains, fixed order
+      a0 += p[(long)m * ld + n];
+      a1 += p[(long)(m + 16) * ld + n];
+    }
+    if (m < M) a0 += p[(long)m * ld + n];
+  }
+  s[rg][c] = a0 + a1;
   __syncthreads();
-  if (rg == 0 && n < N) out[batch * out_bs + n] = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
+  if (rg == 0 && n < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int g2 = 0; g2 < 16; ++g2) t += s[g2][c];
+    out[batch * out_bs + n] = t;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -441,7 +471,7 @@ int drq_ln_tanh_bwd(const float* dh0, int ld0, const float* dh1, int ld1, const 
 int drq_colsum(const float* dy, long ld, long dy_bs, float* out, long out_bs, int M, int N, int nbatch,
                hipStream_t st) {
   if (!dy || !out || M <= 0 || N <= 0 || nbatch <= 0) return DRQ_EARG;
-  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, nbatch), dim3(256), 0, st, dy, ld, dy_bs, out, out_bs, M, N);
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, nbatch), dim3(1024), 0, st, dy, ld, dy_bs, out, out_bs, M, N);
   DRQ_LAUNCH_CHECK();
   return DRQ_OK;
 }

@@ -171,22 +171,75 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  // ---- store: C/D layout col = lane&15, row = (lane>>4)*4 + reg
+  // ---- store: C/D layout col = lane&15, row = (lane>>4)*4 + reg.  Two phases so that every bias / mask
+  // load of the thread is in flight before the first dependent store (no per-element round trips).
+  const int mrow0 = m0 + wm * TM * 16 + (lane >> 4) * 4;
+  const int ncol0 = n0 + wn * TN * 16 + (lane & 15);
+  if (g.splitk > 1) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = mrow0 + i * 16 + r, n = ncol0 + j * 16;
+          if (m < g.M && n < g.N) g.part[((long)z * g.M + m) * g.N + n] = acc[i][j][r];
+        }
+    return;
+  }
+  const Epilogue& e = g.ep;
+  // loads use clamped (always valid) coordinates so that none of them sits behind a per-lane branch
+  float bv[TN];
+  float av[TM][TN][4];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) bv[j] = 0.f;
+  if (e.bias) {
+    const float* bp = e.bias + batch * e.bias_bs;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bv[j] = bp[min(ncol0 + j * 16, g.N - 1)];
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
+      for (int r = 0; r < 4; ++r) av[i][j][r] = 1.f;
+  if (e.aux) {
+    const float* ap = e.aux + batch * e.aux_bs;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          av[i][j][r] = ap[(long)min(mrow0 + i * 16 + r, g.M - 1) * e.ldaux + min(ncol0 + j * 16, g.N - 1)];
+  }
+  float* c = g.C + batch * g.c_bs;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = ncol0 + j * 16;
+      long cbase = n;
+      if (e.scatter_hw > 0) {   // zero-padded (pad 2) NCHW gradient layout, column n = (ch, y, x)
+        const int hw = e.scatter_hw, hp = hw + 4;
+        const int ch = n / (hw * hw);
+        const int rr = n - ch * hw * hw;
+        const int y = rr / hw, x = rr - y * hw;
+        cbase = ((long)ch * hp + (y + 2)) * hp + (x + 2);
+      }
+#pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * TM * 16 + i * 16 + (lane >> 4) * 4 + r;
-        const int n = n0 + wn * TN * 16 + j * 16 + (lane & 15);
+        const int m = mrow0 + i * 16 + r;
         if (m < g.M && n < g.N) {
-          if (g.splitk > 1)
-            g.part[((long)z * g.M + m) * g.N + n] = acc[i][j][r];
-          else
-            epilogue_store(g, batch, m, n, acc[i][j][r]);
+          float v = acc[i][j][r] + bv[j];
+          if (e.relu) v = v > 0.f ? v : 0.f;
+          v = av[i][j][r] > 0.f ? v : 0.f;
+          if (e.scatter_hw > 0) c[(long)m * 32 * (e.scatter_hw + 4) * (e.scatter_hw + 4) + cbase] = v;
+          else c[(long)m * g.ldc + cbase] = v;
         }
       }
+    }
 }
 
 __global__ void splitk_reduce_kernel(GemmArgs g) {
@@ -195,15 +248,19 @@ __global__ void splitk_reduce_kernel(GemmArgs g) {
   const int batch = blockIdx.y;
   if (i >= mn) return;
   const float* p = g.part + (long)batch * g.splitk * mn + i;
-  float s0 = 0.f, s1 = 0.f;
+  // fixed association (4 interleaved chains, then a tree): deterministic, 8 loads in flight
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int k = 0;
-  for (; k + 1 < g.splitk; k += 2) {
+#pragma unroll 2
+  for (; k + 3 < g.splitk; k += 4) {
     s0 += p[(long)k * mn];
     s1 += p[(long)(k + 1) * mn];
+    s2 += p[(long)(k + 2) * mn];
+    s3 += p[(long)(k + 3) * mn];
   }
-  if (k < g.splitk) s0 += p[(long)k * mn];
+  for (; k < g.splitk; ++k) s0 += p[(long)k * mn];
   const int m = (int)(i / g.N), n = (int)(i - (long)m * g.N);
-  epilogue_store(g, batch, m, n, s0 + s1);
+  epilogue_store(g, batch, m, n, (s0 + s1) + (s2 + s3));
 }
 
 template <int TM, int TN, bool A_KC, bool B_KC, bool V4>
