@@ -12,6 +12,7 @@
 // conflict-free MFMA operand reads) -> MFMA.  Split-K writes dense partials; a second kernel sums them
 // in a fixed order (deterministic) and applies the epilogue.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -56,70 +57,77 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, int batch, int
   }
 }
 
-// ---- global -> register tile loaders (BR rows of the block tile, BK columns of k)
+// ---- global -> register tile loaders (BR rows of the block tile, BK columns of k).
+// Loads are unconditional on clamped (always valid) addresses and carry NO dependent ALU: the out-of-range
+// mask is applied when the tile is written to LDS (store_tile).  A load behind a per-lane branch, or a
+// select right after it, makes the compiler wait for it at once and serialises the register queue.
+// Requires rows >= 1 and kend > kbeg (checked by the caller).
 template <int BR, bool KC, bool V4>
 __device__ __forceinline__ void load_tile(const float* P, long ld, int row0, int rows, int k0, int kend,
                                           float (&reg)[BR * BK / 256], int tid) {
   if constexpr (KC && V4) {
-    // 8 threads x float4 along k per row, 32 rows per pass
+    // 8 threads x float4 along k per row, 32 rows per pass (kend % 4 == 0, kend >= 4)
     const int r = tid >> 3, kq = (tid & 7) * 4;
+    const int kc = min(k0 + kq, kend - 4);
 #pragma unroll
     for (int p = 0; p < BR / 32; ++p) {
-      const int row = row0 + p * 32 + r;
-      const int k = k0 + kq;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row < rows && k < kend) v = *reinterpret_cast<const f32x4*>(P + (long)row * ld + k);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(P + (long)min(row0 + p * 32 + r, rows - 1) * ld + kc);
       reg[p * 4 + 0] = v[0]; reg[p * 4 + 1] = v[1]; reg[p * 4 + 2] = v[2]; reg[p * 4 + 3] = v[3];
     }
   } else if constexpr (KC) {
     // 32 lanes along k per row, 8 rows per pass
     const int r = tid >> 5, kk = tid & 31;
+    const int kc = min(k0 + kk, kend - 1);
 #pragma unroll
-    for (int p = 0; p < BR / 8; ++p) {
-      const int row = row0 + p * 8 + r;
-      const int k = k0 + kk;
-      reg[p] = (row < rows && k < kend) ? P[(long)row * ld + k] : 0.f;
-    }
+    for (int p = 0; p < BR / 8; ++p) reg[p] = P[(long)min(row0 + p * 8 + r, rows - 1) * ld + kc];
   } else {
     // row index contiguous in memory: lanes along rows
     const int r = tid % BR, kk0 = tid / BR;
     constexpr int KSTEP = 256 / BR;
+    const int rc = min(row0 + r, rows - 1);
 #pragma unroll
-    for (int p = 0; p < BR * BK / 256; ++p) {
-      const int row = row0 + r;
-      const int k = k0 + kk0 + p * KSTEP;
-      reg[p] = (row < rows && k < kend) ? P[(long)k * ld + row] : 0.f;
-    }
+    for (int p = 0; p < BR * BK / 256; ++p) reg[p] = P[(long)min(k0 + kk0 + p * KSTEP, kend - 1) * ld + rc];
   }
 }
 
+// registers -> LDS [row][k] (pitch PK), zeroing what lies outside the matrix
 template <int BR, bool KC, bool V4>
-__device__ __forceinline__ void store_tile(float* S, const float (&reg)[BR * BK / 256], int tid) {
+__device__ __forceinline__ void store_tile(float* S, const float (&reg)[BR * BK / 256], int row0, int rows, int k0,
+                                           int kend, int tid) {
   if constexpr (KC && V4) {
     const int r = tid >> 3, kq = (tid & 7) * 4;
+    const bool kok = k0 + kq < kend;
 #pragma unroll
     for (int p = 0; p < BR / 32; ++p) {
+      const bool ok = kok && row0 + p * 32 + r < rows;
       float* d = S + (p * 32 + r) * PK + kq;
-      d[0] = reg[p * 4 + 0]; d[1] = reg[p * 4 + 1]; d[2] = reg[p * 4 + 2]; d[3] = reg[p * 4 + 3];
+      d[0] = ok ? reg[p * 4 + 0] : 0.f; d[1] = ok ? reg[p * 4 + 1] : 0.f;
+      d[2] = ok ? reg[p * 4 + 2] : 0.f; d[3] = ok ? reg[p * 4 + 3] : 0.f;
     }
   } else if constexpr (KC) {
     const int r = tid >> 5, kk = tid & 31;
+    const bool kok = k0 + kk < kend;
 #pragma unroll
-    for (int p = 0; p < BR / 8; ++p) S[(p * 8 + r) * PK + kk] = reg[p];
+    for (int p = 0; p < BR / 8; ++p) S[(p * 8 + r) * PK + kk] = (kok && row0 + p * 8 + r < rows) ? reg[p] : 0.f;
   } else {
     const int r = tid % BR, kk0 = tid / BR;
     constexpr int KSTEP = 256 / BR;
+    const bool rok = row0 + r < rows;
 #pragma unroll
-    for (int p = 0; p < BR * BK / 256; ++p) S[r * PK + kk0 + p * KSTEP] = reg[p];
+    for (int p = 0; p < BR * BK / 256; ++p)
+      S[r * PK + kk0 + p * KSTEP] = (rok && k0 + kk0 + p * KSTEP < kend) ? reg[p] : 0.f;
   }
 }
 
 template <int TM, int TN, bool A_KC, bool B_KC, bool V4>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
-  constexpr int RA = BM * BK / 256, RB = BN * BK / 256;   // prefetch registers per thread
-  __shared__ __attribute__((aligned(16))) float As[BM * PK];
-  __shared__ __attribute__((aligned(16))) float Bs[BN * PK];
+  constexpr int RA = BM * BK / 256, RB = BN * BK / 256;   // staging registers per thread and k-tile
+  // Depth of the register queue of k-tiles in flight from global memory.  Small block tiles do little MFMA
+  // work per k-tile (8 MFMAs/wave), so they keep more tiles in flight to cover an L2/HBM round trip.
+  constexpr int D = (TM * TN == 1) ? 4 : 2;
+  __shared__ __attribute__((aligned(16))) float As[2][BM * PK];   // double-buffered: one barrier per k-tile
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN * PK];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
@@ -132,7 +140,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const float* A = g.A + batch * g.a_bs;
   const float* B = g.B + batch * g.b_bs;
 
-  float ra[RA], rb[RB];
+  float ra[D][RA], rb[D][RB];
 
   f32x4 acc[TM][TN];
 #pragma unroll
@@ -142,33 +150,64 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
   const int arow = (wm * TM * 16 + (lane & 15)) * PK + (lane >> 4);
   const int brow = (wn * TN * 16 + (lane & 15)) * PK + (lane >> 4);
+  const int nsteps = (kend - kbeg + BK - 1) / BK;
 
-  if (kbeg < kend) {
-    load_tile<BM, A_KC, V4>(A, g.lda, m0, g.M, kbeg, kend, ra, tid);
-    load_tile<BN, B_KC, V4>(B, g.ldb, n0, g.N, kbeg, kend, rb, tid);
+  // tile t lives in register slot t % D until it is written to LDS buffer t & 1 during step t-1
+  auto fetch = [&](int t, float (&fa)[RA], float (&fb)[RB]) {
+    const int tc = t < nsteps ? t : nsteps - 1;   // past the end: harmless re-load, never written to LDS
+    load_tile<BM, A_KC, V4>(A, g.lda, m0, g.M, kbeg + tc * BK, kend, fa, tid);
+    load_tile<BN, B_KC, V4>(B, g.ldb, n0, g.N, kbeg + tc * BK, kend, fb, tid);
+  };
+  if (nsteps > 0) {
+    fetch(0, ra[0], rb[0]);
+    store_tile<BM, A_KC, V4>(As[0], ra[0], m0, g.M, kbeg, kend, tid);
+    store_tile<BN, B_KC, V4>(Bs[0], rb[0], n0, g.N, kbeg, kend, tid);
+#pragma unroll
+    for (int d = 1; d <= D; ++d) fetch(d, ra[d % D], rb[d % D]);
   }
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    store_tile<BM, A_KC, V4>(As, ra, tid);
-    store_tile<BN, B_KC, V4>(Bs, rb, tid);
-    __syncthreads();
-    if (k0 + BK < kend) {
-      load_tile<BM, A_KC, V4>(A, g.lda, m0, g.M, k0 + BK, kend, ra, tid);
-      load_tile<BN, B_KC, V4>(B, g.ldb, n0, g.N, k0 + BK, kend, rb, tid);
-    }
+  __syncthreads();
+  // one k-tile: MFMAs from LDS buffer (s&1), then move tile t+1 from its register slot to the other
+  // buffer (last read in step t-1; every wave has passed that barrier) and refill the slot with tile t+1+D.
+  // No conditionals inside: a tile past the end is a harmless store into a buffer nobody reads again.
+  auto step = [&](int t, auto sc) {
+    constexpr int s = decltype(sc)::value;
+    const float* as = As[s & 1];      // D is even: t & 1 == s & 1
+    const float* bs = Bs[s & 1];
+    // all operand reads of the k-tile first (one LDS latency per tile, not one per MFMA pair)
+    float a[BK / 4][TM], b[BK / 4][TN];
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
-      float a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = As[arow + i * 16 * PK + kk * 4];
+      for (int i = 0; i < TM; ++i) a[kk][i] = as[arow + i * 16 * PK + kk * 4];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Bs[brow + j * 16 * PK + kk * 4];
+      for (int j = 0; j < TN; ++j) b[kk][j] = bs[brow + j * 16 * PK + kk * 4];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+    store_tile<BM, A_KC, V4>(As[(s + 1) & 1], ra[(s + 1) % D], m0, g.M, kbeg + (t + 1) * BK, kend, tid);
+    store_tile<BN, B_KC, V4>(Bs[(s + 1) & 1], rb[(s + 1) % D], n0, g.N, kbeg + (t + 1) * BK, kend, tid);
+    fetch(t + 1 + D, ra[(s + 1) % D], rb[(s + 1) % D]);
     __syncthreads();
+  };
+  int t0 = 0;
+  for (; t0 + D <= nsteps; t0 += D) {       // full groups: straight-line body, exact vmcnt bookkeeping
+    step(t0 + 0, std::integral_constant<int, 0>{});
+    step(t0 + 1, std::integral_constant<int, 1>{});
+    if constexpr (D == 4) {
+      step(t0 + 2, std::integral_constant<int, 2>{});
+      step(t0 + 3, std::integral_constant<int, 3>{});
+    }
+  }
+  if (t0 + 0 < nsteps) step(t0 + 0, std::integral_constant<int, 0>{});
+  if constexpr (D == 4) {
+    if (t0 + 1 < nsteps) step(t0 + 1, std::integral_constant<int, 1>{});
+    if (t0 + 2 < nsteps) step(t0 + 2, std::integral_constant<int, 2>{});
   }
 
   // ---- store: C/D layout col = lane&15, row = (lane>>4)*4 + reg.  Two phases so that every bias / mask
