@@ -18,7 +18,7 @@ import torch.nn as nn
 
 import utils
 from drqv2_amd import _lib, ops
-from drqv2_amd.engine import StepEngine
+from drqv2_amd.engine import StepEngine, shard_bounds
 from torch.distributions.utils import _standard_normal
 
 
@@ -190,17 +190,12 @@ class DrQV2Agent:
         eng = self._engine
         A = eng.A
         world, rank = eng.world, eng.rank
-        if world > 1 and getattr(self, "_batch_is_global", True):
-            n_global = obs.shape[0]
-            assert n_global % world == 0, "global batch must divide evenly over the ranks"
-            per = n_global // world
-            lo, hi = rank * per, (rank + 1) * per
+        big = getattr(self, "_batch_is_global", True)
+        lo, hi, n_global = shard_bounds(obs.shape[0], world, rank, big)
+        if world > 1 and big:
             obs_l, action_l, reward_l, discount_l, next_l = (t[lo:hi] for t in (obs, action, reward, discount,
                                                                                  next_obs))
         else:
-            per = obs.shape[0]
-            n_global = per * world
-            lo, hi = rank * per, (rank + 1) * per
             obs_l, action_l, reward_l, discount_l, next_l = obs, action, reward, discount, next_obs
         # every rank draws for the GLOBAL batch and keeps its slice: same numbers as the 1-GPU run
         sh_o, sh_n, n_c, n_a = (t.reshape(n_global, -1)[lo:hi].contiguous() for t in self._draws(n_global, A))

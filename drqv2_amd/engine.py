@@ -49,6 +49,26 @@ class FlatAdam(torch.optim.Optimizer):
         self._v.copy_(st["v"])
 
 
+def shard_bounds(n_rows, world, rank, batch_is_global):
+    """Rows [lo,hi) of the GLOBAL batch that `rank` trains on, and the global batch size.
+    batch_is_global: the iterator yields the same global batch on every rank (n_rows rows);
+    otherwise it yields this rank's shard (n_rows rows each)."""
+    if world > 1 and batch_is_global:
+        if n_rows % world != 0:
+            raise ValueError("global batch must divide evenly over the ranks")
+        per, n_global = n_rows // world, n_rows
+    else:
+        per, n_global = n_rows, n_rows * world
+    return rank * per, (rank + 1) * per, n_global
+
+
+def grad_buckets(layout):
+    """The two all-reduce buckets of one update as [beg,end) ranges of the gradient arena:
+    (encoder+critic) after the critic backward, (actor) after the actor backward."""
+    seg = layout["seg"]
+    return (seg["enc"][0], seg["critic"][1]), (seg["actor"][0], seg["actor"][1])
+
+
 class StepEngine:
     def __init__(self, encoder, actor, critic, critic_target, obs_shape, action_dim, feature_dim, hidden_dim, lr,
                  device):
@@ -147,7 +167,9 @@ class StepEngine:
         d.lr, d.tau = float(self.critic_opt.lr), float(tau)
         d.std, d.clip = float(std), float(clip)
         d.step_critic, d.step_enc, d.step_actor = steps
-        d.gscale = 1.0 / self.world
+        # local gradients are already scaled by 1/global_B (drq_td_mse / drq_actor_loss), so the SUM
+        # all-reduce over ranks yields the global-batch mean gradient: no further scaling
+        d.gscale = 1.0
         d.stream = torch.cuda.current_stream().cuda_stream
         return d
 
@@ -168,11 +190,11 @@ class StepEngine:
         if self.world == 1:
             check(lib.drq_update_phase(ref, -1), "drq_update_phase")
         else:
-            seg = self.layout["seg"]
+            b1, b2 = grad_buckets(self.layout)
             check(lib.drq_update_phase(ref, 0), "drq_update_phase(0)")
-            self._allreduce(self.grads[seg["enc"][0]:seg["critic"][1]])       # bucket 1: encoder + critic
+            self._allreduce(self.grads[b1[0]:b1[1]])      # bucket 1: encoder + critic
             check(lib.drq_update_phase(ref, 1), "drq_update_phase(1)")
-            self._allreduce(self.grads[seg["actor"][0]:seg["actor"][1]])      # bucket 2: actor
+            self._allreduce(self.grads[b2[0]:b2[1]])      # bucket 2: actor
             self._allreduce(self.sums)
             check(lib.drq_update_phase(ref, 2), "drq_update_phase(2)")
         del keep

@@ -1,0 +1,169 @@
+"""CPU-only checks of the drop-in boundary: constructor/method signatures and state_dict layout against
+fixtures captured from the reference (tests/golden/interface.json), the C ABI export table against
+include/drqv2_hip.h, the config surface, pickling, and the loud failure of the update path without a GPU."""
+import inspect
+import json
+import os
+import pickle
+import re
+
+import pytest
+import torch
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def iface():
+    with open(os.path.join(G, "interface.json")) as f:
+        return json.load(f)
+
+
+def _sig(f):
+    return [[n, None if p.default is inspect._empty else repr(p.default)]
+            for n, p in inspect.signature(f).parameters.items()]
+
+
+def test_signatures_match_reference(iface):
+    import drqv2
+    import utils
+    objs = {"DrQV2Agent.__init__": drqv2.DrQV2Agent.__init__, "DrQV2Agent.act": drqv2.DrQV2Agent.act,
+            "DrQV2Agent.update": drqv2.DrQV2Agent.update, "DrQV2Agent.train": drqv2.DrQV2Agent.train,
+            "RandomShiftsAug.__init__": drqv2.RandomShiftsAug.__init__, "Encoder.__init__": drqv2.Encoder.__init__,
+            "Actor.__init__": drqv2.Actor.__init__, "Actor.forward": drqv2.Actor.forward,
+            "Critic.__init__": drqv2.Critic.__init__, "Critic.forward": drqv2.Critic.forward,
+            "utils.soft_update_params": utils.soft_update_params, "utils.to_torch": utils.to_torch,
+            "utils.schedule": utils.schedule, "utils.weight_init": utils.weight_init,
+            "utils.TruncatedNormal.__init__": utils.TruncatedNormal.__init__,
+            "utils.TruncatedNormal.sample": utils.TruncatedNormal.sample,
+            "utils.set_seed_everywhere": utils.set_seed_everywhere, "utils.Until.__init__": utils.Until.__init__,
+            "utils.Every.__init__": utils.Every.__init__}
+    for name, fn in objs.items():
+        assert _sig(fn) == iface["signatures"][name], name
+    for n in iface["utils_names"]:          # every public name train.py can reach
+        assert hasattr(utils, n), n
+
+
+def test_state_dict_init_stream_and_attrs(iface):
+    import drqv2
+    torch.manual_seed(1)
+    ag = drqv2.DrQV2Agent((9, 84, 84), (6,), "cpu", 1e-4, 50, 1024, 0.01, 2000, 2, "linear(1.0,0.1,500000)", 0.3, True)
+    for nm in ("encoder", "actor", "critic", "critic_target"):
+        got = [[k, list(v.shape)] for k, v in getattr(ag, nm).state_dict().items()]
+        assert got == iface["state_dict"][nm], nm
+    # same global-RNG consumption as the reference constructors -> same initial weights under seed 1
+    for nm in ("encoder", "actor", "critic"):
+        for p, r in zip(getattr(ag, nm).parameters(), iface["init_seed1"][nm]):
+            assert float(p.detach().double().norm()) == pytest.approx(r["l2"], rel=1e-9, abs=1e-12), nm
+    for a, b in zip(ag.critic.parameters(), ag.critic_target.parameters()):
+        assert torch.equal(a, b)
+    assert ag.encoder.repr_dim == iface["repr_dim"]
+    for attr in iface["agent_attrs"]:
+        assert hasattr(ag, attr), attr
+    assert ag.training is True
+    ag.train(False)
+    assert ag.training is False and not ag.encoder.training
+    # parameters live in one arena, gradients are views of the gradient arena
+    eng = ag._engine
+    p0 = next(ag.critic.parameters())
+    assert p0.data_ptr() == eng.params.data_ptr() + 4 * eng.layout["critic"][0]
+    assert p0.grad.data_ptr() == eng.grads.data_ptr() + 4 * eng.layout["critic"][0]
+
+
+def test_update_and_act_fail_loudly_without_gpu():
+    import drqv2
+    from drqv2_amd._lib import DrqError
+    from drqv2_amd import synth
+    ag = drqv2.DrQV2Agent((9, 84, 84), (3,), "cpu", 1e-3, 20, 64, 0.01, 2000, 2, "0.2", 0.3, True)
+    assert ag.update(iter([]), 1) == {}          # gated step: no batch is drawn (drqv2.py:233-234)
+    batch = synth.make_batch(2, 3)
+    with pytest.raises(DrqError):
+        ag.update(iter([tuple(x.numpy() for x in batch)]), 0)
+    with pytest.raises(DrqError):
+        ag.act(batch[0][0].numpy(), 0, True)
+    import utils
+    with pytest.raises(DrqError):
+        utils.soft_update_params(torch.nn.Linear(4, 4), torch.nn.Linear(4, 4), 0.01)
+
+
+def test_pickle_roundtrip_cpu():
+    import drqv2
+    ag = drqv2.DrQV2Agent((9, 84, 84), (3,), "cpu", 1e-3, 20, 64, 0.01, 2000, 2, "0.2", 0.3, False)
+    ag.critic_opt.t = 7
+    with torch.no_grad():
+        ag._engine.adam_m.uniform_(-1, 1)
+    state = torch.get_rng_state()
+    ag2 = pickle.loads(pickle.dumps(ag))
+    assert torch.equal(torch.get_rng_state(), state)             # loading must not move the global RNG
+    for a, b in zip(ag.actor.parameters(), ag2.actor.parameters()):
+        assert torch.equal(a, b)
+    seg = ag._engine.layout["seg"]["critic"]
+    assert ag2.critic_opt.t == 7
+    assert torch.equal(ag2._engine.adam_m[seg[0]:seg[1]], ag._engine.adam_m[seg[0]:seg[1]])
+    assert ag2.use_tb is False and ag2.stddev_schedule == "0.2"
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """include/drqv2_hip.h <-> libdrqv2_hip.so <-> the ctypes prototype table."""
+    from drqv2_amd import _lib
+    lib = _lib.load()
+    with open(os.path.join(ROOT, "include", "drqv2_hip.h")) as f:
+        hdr = f.read()
+    declared = set(re.findall(r"\b(drq_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert set(_lib.PROTOTYPES) == declared
+    assert lib.drq_abi_version() == 1
+    # layout entry points are host-only and callable without a GPU
+    lay = _lib.param_layout(9, 6, 50, 1024)
+    assert lay["seg"]["enc"][0] == 0 and lay["total"] == lay["seg"]["target"][1]
+    n_enc = 32 * 9 * 9 + 32 + 3 * (32 * 32 * 9 + 32)
+    assert lay["seg"]["enc"][1] >= n_enc
+    assert lib.drq_step_ws_bytes(256, 9, 6, 50, 1024) > 0
+    assert lib.drq_step_ws_bytes(0, 9, 6, 50, 1024) == 0
+    # argument errors are reported, not executed (no GPU needed: the check precedes any launch)
+    assert lib.drq_gemm_f32(None, 1, 1, None, 1, 1, None, 1, 4, 4, 4, 1, 0, 0, 0, None, 0, 0, None, 0, 0, 0, 0, 0,
+                            None, 0, None) == -1
+    assert lib.drq_conv3x3_fwd(None, None, None, None, 1, 9, 84, 2, 1, 1, 1, 1, 0, None) == -1
+
+
+def test_config_surface_matches_reference_yaml():
+    from drqv2_amd import tasks
+    with open(os.path.join(G, "cfg_surface.json")) as f:
+        surf = json.load(f)
+    assert sorted(tasks.TASKS) == sorted(surf["tasks"])
+    for name, ref in surf["tasks"].items():
+        cfg = tasks.resolve(name)
+        for k in ("lr", "feature_dim", "stddev_schedule", "batch_size", "nstep", "num_train_frames", "frame_stack",
+                  "action_repeat", "discount", "replay_buffer_size", "task_name"):
+            want = float(ref[k]) if k == "lr" else ref[k]      # PyYAML reads the YAML 1e-4 as a string
+            assert cfg[k] == want, (name, k, cfg[k], ref[k])
+        for k, v in ref["agent"].items():
+            if isinstance(v, str) and v.startswith("${"):
+                continue
+            if v == "???":
+                continue
+            assert cfg["agent"][k] == v, (name, k)
+        kw = tasks.agent_kwargs(name, obs_shape=(9, 84, 84), action_shape=(6,), device="cpu")
+        assert kw["lr"] == float(ref["lr"]) and kw["feature_dim"] == ref["feature_dim"]
+        assert kw["stddev_schedule"] == ref["stddev_schedule"]
+
+
+def test_schedule_and_helpers_match_reference():
+    import utils
+    with open(os.path.join(G, "schedule.json")) as f:
+        ref = json.load(f)
+    for s, vals in ref.items():
+        for st, v in zip((0, 1, 999, 50000, 100000, 3000000), vals):
+            assert float(utils.schedule(s, st)) == pytest.approx(v, rel=1e-15, abs=0)
+    with pytest.raises(NotImplementedError):
+        utils.schedule("cosine(1,2)", 3)
+    u, e = utils.Until(100, 2), utils.Every(10, 2)
+    assert u(49) and not u(50) and e(0) and e(5) and not e(6)
+    assert utils.Until(None)(10 ** 9) and not utils.Every(None)(0)
+    m = torch.nn.Linear(3, 3)
+    with utils.eval_mode(m):
+        assert not m.training
+    assert m.training
