@@ -41,7 +41,8 @@ struct ConvArgs {
 };
 
 // BLK = workgroups per CU the kernel is tuned for (8 waves each): 2 -> 4 waves/SIMD (<=128 VGPR)
-template <int CIN, int HIN, int STRIDE, int BLK, int TPW>
+// ABL (development only): 1 = skip the input loads, 2 = skip the LDS weight reads, 3 = both (timing ablations)
+template <int CIN, int HIN, int STRIDE, int BLK, int TPW, int ABL = 0>
 __global__ __launch_bounds__(512, 2 * BLK) void conv3x3_kernel(ConvArgs a) {
   constexpr int CP = (CIN + 1) / 2;
   constexpr int NS = CP * 9;                 // MFMA steps per tile
@@ -55,13 +56,27 @@ __global__ __launch_bounds__(512, 2 * BLK) void conv3x3_kernel(ConvArgs a) {
   const int col = lane & 31;   // MFMA: A row (cout) for the weights, B column (pixel) for the input
   const int half = lane >> 5;  // k parity -> channel parity
 
-  for (int idx = threadIdx.x; idx < NS * 64; idx += 512) {
-    const int step = idx >> 6, l = idx & 63;
-    const int c = step / 9, t = step - 9 * c;
-    const int kc = 2 * c + (l >> 5), row = l & 31;
-    float v = 0.f;
-    if (kc < CIN) v = a.w[(a.wmode == 0) ? (row * CIN + kc) * 9 + t : (kc * 32 + row) * 9 + (8 - t)];
-    wl[idx] = v;
+  // weight gather -> LDS: fixed trip count, fully unrolled, so all of a thread's loads are in flight at once
+  // (a rolled loop serialises ~18 L2 round trips at the start of every workgroup)
+  {
+    constexpr int NIT = (NS * 64 + 511) / 512;
+    float wv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = min(it * 512 + (int)threadIdx.x, NS * 64 - 1);
+      const int step = idx >> 6, l = idx & 63;
+      const int c = step / 9, t = step - 9 * c;
+      const int kc = min(2 * c + (l >> 5), CIN - 1), row = l & 31;
+      wv[it] = a.w[(a.wmode == 0) ? (row * CIN + kc) * 9 + t : (kc * 32 + row) * 9 + (8 - t)];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = it * 512 + (int)threadIdx.x;
+      if (idx < NS * 64) {
+        const int step = idx >> 6, l = idx & 63;
+        wl[idx] = (2 * (step / 9) + (l >> 5) < CIN) ? wv[it] : 0.f;
+      }
+    }
   }
   if (threadIdx.x < 32) bl[threadIdx.x] = a.bias ? a.bias[threadIdx.x] : 0.f;
   __syncthreads();
@@ -98,6 +113,12 @@ __global__ __launch_bounds__(512, 2 * BLK) void conv3x3_kernel(ConvArgs a) {
     // (3x fewer vector-memory instructions than per-tap dword loads; the TA was the limiter)
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
+      if constexpr (ABL & 1) {
+        dst[ky * 3 + 0] = __uint_as_float(voff + cbase);
+        dst[ky * 3 + 1] = __uint_as_float(voff + ky);
+        dst[ky * 3 + 2] = __uint_as_float(cbase + ky);
+        continue;
+      }
       const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rsrc, voff, cbase + ky * HIN * 4, 0);
       // (elements are copied to scalars first: __builtin_bit_cast on a vector-element lvalue
       //  reads element 0 for every index with this clang)
@@ -113,7 +134,7 @@ __global__ __launch_bounds__(512, 2 * BLK) void conv3x3_kernel(ConvArgs a) {
     const float* wp = wlane + c * (9 * 64);
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const float wv = wp[t * 64];
+      const float wv = (ABL & 2) ? __uint_as_float((unsigned)(c * 9 + t) + lane) : wp[t * 64];
 #pragma unroll
       for (int j = 0; j < TPW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, xv[j][t], acc[j], 0, 0, 0);
     }
@@ -216,29 +237,43 @@ struct WgradArgs {
   const float* dy;    // grad of the pre-activation, [NB][32][dy rows][dy cols] addressed with strides
   long dy_bs, dy_cs, dy_rs, dy_off;
   float* part;        // [nblocks][PART]
+  unsigned x_bytes, dy_bytes;
   int nb;
 };
+
+constexpr int even_odd_half(int n) {   // smallest even p >= n with p/2 odd  (LDS row pitch, see below)
+  int p = (n + 1) & ~1;
+  return (p / 2) % 2 ? p : p + 2;
+}
 
 template <int CIN, int HIN, int STRIDE>
 struct WgradGeom {
   static constexpr int HOUT = (HIN - 3) / STRIDE + 1;
   static constexpr int KS = (HOUT + 1) / 2;                 // k-steps (pixel pairs) per output row
-  static constexpr int XW = (2 * KS - 1) * STRIDE + 3;      // columns touched (>= HIN)
-  static constexpr int XP = (XW | 1);                       // odd LDS pitch of an input row
-  static constexpr int DP = ((2 * KS) | 1);                 // odd LDS pitch of a dY row
+  static constexpr int XW = (2 * KS - 1) * STRIDE + 3;      // input columns touched (>= HIN)
+  // Rows are staged with 8-byte loads/LDS writes (3x fewer instructions than dwords), so row starts must be
+  // 8-byte aligned: even pitch.  pitch/2 odd keeps the channel-strided MFMA operand reads at 2-way conflicts.
+  static constexpr int XPAIRS = (HIN + 1) / 2;              // 8-byte pieces per input row
+  static constexpr int DPAIRS = (HOUT + 1) / 2;
+  static constexpr int XP = even_odd_half(XW > 2 * XPAIRS ? XW : 2 * XPAIRS);
+  static constexpr int DP = even_odd_half(2 * KS + 1 > 2 * DPAIRS ? 2 * KS + 1 : 2 * DPAIRS);
+  static constexpr int XRPI = 64 / XPAIRS;                  // input rows per load instruction
+  static constexpr int DRPI = 64 / DPAIRS;
+  static constexpr int XJ = (CIN + XRPI - 1) / XRPI;        // load instructions per kernel row ky
+  static constexpr int DJ = (32 + DRPI - 1) / DRPI;
   static constexpr bool SMALL = (CIN * 3 <= 32);            // conv1: columns = (ci,kx), tiles = ky
   static constexpr int NT = SMALL ? 3 : 9;
   static constexpr int XS = 3 * CIN * XP;                   // floats of X per wave
   static constexpr int WAVE_LDS = XS + 32 * DP;             // floats per wave
   static constexpr int PART = NT * 1024 + 64;               // floats per partial record
-  static constexpr int XSEG = (HIN + 63) / 64;              // 64-lane pieces per input row
-  static constexpr int NXR = 3 * CIN * XSEG;                // staging registers for X
 };
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 template <int CIN, int HIN, int STRIDE>
 __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(WgradArgs a) {
   using G = WgradGeom<CIN, HIN, STRIDE>;
-  constexpr int HOUT = G::HOUT, KS = G::KS, XP = G::XP, DP = G::DP, NT = G::NT, XSEG = G::XSEG;
+  constexpr int HOUT = G::HOUT, KS = G::KS, XP = G::XP, DP = G::DP, NT = G::NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
@@ -273,36 +308,55 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(WgradArgs a) {
   const long gw = (long)blockIdx.x * 4 + wid;
   const long u0 = units * gw / nw, u1 = units * (gw + 1) / nw;
 
-  // ---- register staging: one (ky,ci) input row piece / one dY row per load instruction
-  float rx[G::NXR], rd[32];
+  // ---- register staging with 8-byte pieces: lane = (row within the instruction, pair within the row)
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
+  const int xr = lane / G::XPAIRS, xpr = lane - xr * G::XPAIRS;      // xr >= XRPI: idle lane
+  const int dr = lane / G::DPAIRS, dpr = lane - dr * G::DPAIRS;
+  const bool xact = xr < G::XRPI, dact = dr < G::DRPI;
+  const int xg_lane = (xr * HIN * HIN + 2 * xpr) * 4;                // global byte offsets (lane part)
+  const int dg_lane = (int)(dr * a.dy_cs + 2 * dpr) * 4;
+  const int xl_lane = xr * XP + 2 * xpr;                             // LDS float offsets (lane part)
+  const int dl_lane = dr * DP + 2 * dpr;
+  const bool d_last_odd = (HOUT & 1) && dpr == G::DPAIRS - 1;        // second float of the pair is column HOUT
+
+  u32x2 rx[3 * G::XJ], rd[G::DJ];
   auto issue_loads = [&](long u) {
     const int b = (int)(u / HOUT);
     const int oy = (int)(u - (long)b * HOUT);
-    const float* xg = a.x + ((long)b * CIN * HIN + (long)oy * STRIDE) * HIN;
+    const int xbase = ((b * CIN * HIN + oy * STRIDE) * HIN) * 4;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-      for (int ci = 0; ci < CIN; ++ci)
+      for (int j = 0; j < G::XJ; ++j) {
+        // rows (ky, ci = j*XRPI + xr); lanes past the last channel or the last row of the instruction are
+        // sent out of range (descriptor returns 0, nothing is written for them)
+        const bool ok = xact && j * G::XRPI + xr < CIN;
+        const int voff = ok ? xbase + xg_lane : 0x7ffffff0;
+        rx[ky * G::XJ + j] = __builtin_amdgcn_raw_buffer_load_b64(xrsrc, voff, (j * G::XRPI * HIN * HIN + ky * HIN) * 4, 0);
+      }
+    const int dbase = (int)(a.dy_off + (long)b * a.dy_bs + (long)oy * a.dy_rs) * 4;
 #pragma unroll
-        for (int sg = 0; sg < XSEG; ++sg) {
-          const int xx = sg * 64 + lane;
-          rx[(ky * CIN + ci) * XSEG + sg] = xx < HIN ? xg[((long)ci * HIN + ky) * HIN + xx] : 0.f;
-        }
-    const float* dg = a.dy + a.dy_off + (long)b * a.dy_bs + (long)oy * a.dy_rs;
-#pragma unroll
-    for (int co = 0; co < 32; ++co) rd[co] = lane < HOUT ? dg[(long)co * a.dy_cs + lane] : 0.f;
+    for (int j = 0; j < G::DJ; ++j) {
+      const bool ok = dact && j * G::DRPI + dr < 32;
+      const int voff = ok ? dbase + dg_lane + (int)(j * G::DRPI * a.dy_cs) * 4 : 0x7ffffff0;
+      rd[j] = __builtin_amdgcn_raw_buffer_load_b64(drsrc, voff, 0, 0);
+    }
   };
   auto write_lds = [&]() {
 #pragma unroll
-    for (int r = 0; r < 3 * CIN; ++r)
+    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-      for (int sg = 0; sg < XSEG; ++sg) {
-        const int xx = sg * 64 + lane;
-        if (xx < HIN) xs[r * XP + xx] = rx[r * XSEG + sg];
+      for (int j = 0; j < G::XJ; ++j)
+        if (xact && j * G::XRPI + xr < CIN)
+          *reinterpret_cast<u32x2*>(xs + (ky * CIN + j * G::XRPI) * XP + xl_lane) = rx[ky * G::XJ + j];
+#pragma unroll
+    for (int j = 0; j < G::DJ; ++j)
+      if (dact && j * G::DRPI + dr < 32) {
+        u32x2 v = rd[j];
+        if (d_last_odd) v[1] = 0u;      // column HOUT of an odd row must stay zero (it pairs with the pad pixel)
+        *reinterpret_cast<u32x2*>(ds + j * G::DRPI * DP + dl_lane) = v;
       }
-#pragma unroll
-    for (int co = 0; co < 32; ++co)
-      if (lane < HOUT) ds[co * DP + lane] = rd[co];
   };
 
   if (u0 < u1) issue_loads(u0);
@@ -336,6 +390,167 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(WgradArgs a) {
   float* out = a.part + (long)blockIdx.x * G::PART;
   for (int i = threadIdx.x; i < G::PART; i += 256)
     out[i] = (red[i] + red[G::PART + i]) + (red[2 * G::PART + i] + red[3 * G::PART + i]);
+}
+
+// ---- wgrad v2: the four waves of a workgroup take four consecutive output rows of one sample and SHARE
+// the staged input rows (3+3*STRIDE rows instead of 12); the LDS footprint (<= 74 KB incl. the final
+// reduction) lets two workgroups live on a CU, so one workgroup's staging/barriers hide under the other's
+// MFMA loop.
+template <int CIN, int HIN, int STRIDE>
+struct Wgrad2Geom : WgradGeom<CIN, HIN, STRIDE> {
+  using G = WgradGeom<CIN, HIN, STRIDE>;
+  static constexpr int NR = 3 * STRIDE + 3;                    // input rows per group of 4 output rows
+  static constexpr int NG = (G::HOUT + 3) / 4;                 // groups per sample
+  static constexpr int XQ = (NR * G::XJ + 3) / 4;              // X load instructions per wave and group
+  static constexpr int XS2 = NR * CIN * G::XP;                 // floats of the shared input tile
+  static constexpr int TILE = XS2 + 4 * 32 * G::DP;            // + one dY row per wave
+  static constexpr int LDS_FLOATS = TILE > 2 * G::PART ? TILE : 2 * G::PART;
+};
+
+template <int CIN, int HIN, int STRIDE>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad2_kernel(WgradArgs a) {
+  using G = Wgrad2Geom<CIN, HIN, STRIDE>;
+  constexpr int HOUT = G::HOUT, KS = G::KS, XP = G::XP, DP = G::DP, NT = G::NT;
+  constexpr int XJ = G::XJ, DJ = G::DJ, XRPI = G::XRPI, DRPI = G::DRPI, NR = G::NR, XQ = G::XQ;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  const int col = lane & 31;
+  const int half = lane >> 5;
+  float* xs = smem;
+  float* ds = smem + G::XS2 + wid * 32 * DP;
+
+  // pad columns must hold finite values (they meet dY == 0): zero the tile once
+  for (int i = threadIdx.x; i < G::TILE; i += 256) smem[i] = 0.f;
+
+  int bbase;   // B operand: X[pixel][column], rows of this wave start at input row wid*STRIDE of the tile
+  if (G::SMALL) {
+    const int ci = col < CIN * 3 ? col / 3 : 0;
+    const int kx = col < CIN * 3 ? col % 3 : 0;
+    bbase = (wid * STRIDE * CIN + ci) * XP + kx + half * STRIDE;
+  } else {
+    bbase = (wid * STRIDE * CIN + (col < CIN ? col : 0)) * XP + half * STRIDE;
+  }
+  const int abase = col * DP + half;   // A operand: dY[cout][pixel]
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;
+
+  const int ngroups = a.nb * G::NG;
+  const int g0 = (int)((long)ngroups * blockIdx.x / gridDim.x);
+  const int g1 = (int)((long)ngroups * (blockIdx.x + 1) / gridDim.x);
+
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
+  const int xr = lane / G::XPAIRS, xpr = lane - xr * G::XPAIRS;      // xr >= XRPI: idle lane
+  const int dr = lane / G::DPAIRS, dpr = lane - dr * G::DPAIRS;
+  const bool xact = xr < XRPI, dact = dr < DRPI;
+  const int xg_lane = (xr * HIN * HIN + 2 * xpr) * 4;                // global byte offsets (lane part)
+  const int dg_lane = (int)(dr * a.dy_cs + 2 * dpr) * 4;
+  const int xl_lane = xr * XP + 2 * xpr;                             // LDS float offsets (lane part)
+  const int dl_lane = dr * DP + 2 * dpr;
+  const bool d_last_odd = (HOUT & 1) && dpr == G::DPAIRS - 1;
+
+  u32x2 rx[XQ], rd[DJ];
+  // instruction q of this wave covers tile row (q*4+wid) / XJ and channel block (q*4+wid) % XJ
+  auto issue_loads = [&](int g) {
+    const int b = g / G::NG;
+    const int oy0 = (g - b * G::NG) * 4;
+    const int xbase = ((b * CIN * HIN + oy0 * STRIDE) * HIN) * 4;
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) {
+      const int it = q * 4 + wid;
+      const int trow = it / XJ, j = it - trow * XJ;
+      const bool ok = xact && it < NR * XJ && j * XRPI + xr < CIN && oy0 * STRIDE + trow < HIN;
+      const int voff = ok ? xbase + xg_lane + (j * XRPI * HIN * HIN + trow * HIN) * 4 : 0x7ffffff0;
+      rx[q] = __builtin_amdgcn_raw_buffer_load_b64(xrsrc, voff, 0, 0);
+    }
+    const int oy = oy0 + wid;
+    const int dbase = (int)(a.dy_off + (long)b * a.dy_bs + (long)oy * a.dy_rs) * 4;
+#pragma unroll
+    for (int j = 0; j < DJ; ++j) {
+      const bool ok = dact && j * DRPI + dr < 32 && oy < HOUT;
+      const int voff = ok ? dbase + dg_lane + (int)(j * DRPI * a.dy_cs) * 4 : 0x7ffffff0;
+      rd[j] = __builtin_amdgcn_raw_buffer_load_b64(drsrc, voff, 0, 0);
+    }
+  };
+  auto write_lds = [&]() {
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) {
+      const int it = q * 4 + wid;
+      const int trow = it / XJ, j = it - trow * XJ;
+      if (xact && it < NR * XJ && j * XRPI + xr < CIN)
+        *reinterpret_cast<u32x2*>(xs + (trow * CIN + j * XRPI) * XP + xl_lane) = rx[q];
+    }
+#pragma unroll
+    for (int j = 0; j < DJ; ++j)
+      if (dact && j * DRPI + dr < 32) {
+        u32x2 v = rd[j];
+        if (d_last_odd) v[1] = 0u;      // column HOUT of an odd row must stay zero (it pairs with the pad pixel)
+        *reinterpret_cast<u32x2*>(ds + j * DRPI * DP + dl_lane) = v;
+      }
+  };
+
+  __syncthreads();                       // tile zeroed
+  for (int g = g0; g < g1; ++g) {
+    // no cross-group register prefetch (144 accumulators leave no room at 2 waves/SIMD): the load latency
+    // of this workgroup is covered by the MFMA loop of the other workgroup on the CU
+    issue_loads(g);
+    write_lds();
+    __syncthreads();                     // tile of group g complete
+    const int oy = (g % G::NG) * 4 + wid;
+    if (oy < HOUT) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const float av = ds[abase + 2 * s];
+        bsum += av;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int off = G::SMALL ? (t * CIN * XP + 2 * s * STRIDE)
+                                   : ((t / 3) * CIN * XP + (t % 3) + 2 * s * STRIDE);
+          const float bv = xs[bbase + off];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();                     // every wave done reading the tile
+  }
+
+  // ---- 4 waves -> 1 record, two rounds through LDS (2 records = 74 KB), fixed order
+  float* red = smem;
+  auto put = [&](int slot) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[slot * G::PART + t * 1024 + r * 64 + lane] = acc[t][r];
+    red[slot * G::PART + NT * 1024 + lane] = bsum;
+  };
+  auto add = [&](int slot) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] += red[slot * G::PART + t * 1024 + r * 64 + lane];
+    bsum += red[slot * G::PART + NT * 1024 + lane];
+  };
+  if (wid >= 2) put(wid - 2);
+  __syncthreads();
+  if (wid < 2) add(wid);                 // wave0 += wave2, wave1 += wave3
+  __syncthreads();
+  if (wid == 1) put(0);
+  __syncthreads();
+  if (wid == 0) {
+    add(0);
+    float* out = a.part + (long)blockIdx.x * G::PART;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[t * 1024 + r * 64 + lane] = acc[t][r];
+    out[NT * 1024 + lane] = bsum;
+  }
 }
 
 // Sums the per-block partial records in a fixed order and scatters to the canonical layouts.
@@ -372,7 +587,7 @@ __global__ __launch_bounds__(1024) void conv3x3_wgrad_reduce_kernel(const float*
   }
 }
 
-template <int CIN, int HIN, int STRIDE, int BLK, int TPW>
+template <int CIN, int HIN, int STRIDE, int BLK, int TPW, int ABL = 0>
 int launch_conv_v(const ConvArgs& a, hipStream_t st) {
   constexpr int HOUT = (HIN - 3) / STRIDE + 1;
   const long ntiles = ((long)a.nb * HOUT * HOUT + 31) / 32;
@@ -380,7 +595,7 @@ int launch_conv_v(const ConvArgs& a, hipStream_t st) {
   const long cap = (long)BLK * drq_num_cus();
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((conv3x3_kernel<CIN, HIN, STRIDE, BLK, TPW>), dim3((unsigned)blocks), dim3(512), 0, st, a);
+  hipLaunchKernelGGL((conv3x3_kernel<CIN, HIN, STRIDE, BLK, TPW, ABL>), dim3((unsigned)blocks), dim3(512), 0, st, a);
   DRQ_LAUNCH_CHECK();
   return DRQ_OK;
 }
@@ -403,20 +618,37 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     case 3: return launch_conv_v<CIN, HIN, STRIDE, 3, 1>(a, st);
     case 4: return launch_conv_v<CIN, HIN, STRIDE, 1, 4>(a, st);
     case 5: return launch_conv_v<CIN, HIN, STRIDE, 4, 1>(a, st);
+    case 6: return launch_conv_v<CIN, HIN, STRIDE, 2, 1, 1>(a, st);
+    case 7: return launch_conv_v<CIN, HIN, STRIDE, 2, 1, 2>(a, st);
+    case 8: return launch_conv_v<CIN, HIN, STRIDE, 2, 1, 3>(a, st);
+    case 9: return launch_conv_v<CIN, HIN, STRIDE, 1, 4, 3>(a, st);
     default: return launch_conv_v<CIN, HIN, STRIDE, 2, 1>(a, st);
   }
+}
+
+inline int wgrad_variant() {     // DRQ_WGRAD_VARIANT (development knob, read once): 2 = block-shared input rows
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("DRQ_WGRAD_VARIANT");
+    v = e ? atoi(e) : 1;
+  }
+  return v;
 }
 
 template <int CIN, int HIN, int STRIDE>
 int launch_wgrad(const WgradArgs& a0, float* dw, float* db, float* ws, size_t ws_bytes, hipStream_t st) {
   using G = WgradGeom<CIN, HIN, STRIDE>;
+  using G2 = Wgrad2Geom<CIN, HIN, STRIDE>;
   static_assert(4 * G::WAVE_LDS * 4 <= 160 * 1024, "LDS tile too large");
   static_assert(4 * G::PART * 4 <= 160 * 1024, "reduction tile too large");
+  static_assert(G2::LDS_FLOATS * 4 <= 80 * 1024, "two workgroups per CU need <= 80 KB each");
   static_assert(G::PART % 64 == 0, "record size");
-  constexpr int lds_floats = (4 * G::WAVE_LDS > 4 * G::PART) ? 4 * G::WAVE_LDS : 4 * G::PART;
-  const long units = (long)a0.nb * G::HOUT;
-  long blocks = drq_num_cus();
-  if (blocks * 4 > units) blocks = (units + 3) / 4;
+  const bool v2 = wgrad_variant() == 2;
+  constexpr int lds1 = (4 * G::WAVE_LDS > 4 * G::PART) ? 4 * G::WAVE_LDS : 4 * G::PART;
+  const int lds_floats = v2 ? G2::LDS_FLOATS : lds1;
+  const long units = v2 ? (long)a0.nb * G2::NG : ((long)a0.nb * G::HOUT + 3) / 4;
+  long blocks = (v2 ? 2L : 1L) * drq_num_cus();
+  if (blocks > units) blocks = units;
   if (blocks < 1) blocks = 1;
   if ((size_t)blocks * G::PART * sizeof(float) > ws_bytes) return DRQ_EWS;
   WgradArgs a = a0;
@@ -424,12 +656,19 @@ int launch_wgrad(const WgradArgs& a0, float* dw, float* db, float* ws, size_t ws
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel<CIN, HIN, STRIDE>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_floats * 4);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds1 * 4);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)conv3x3_wgrad2_kernel<CIN, HIN, STRIDE>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, G2::LDS_FLOATS * 4);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_wgrad_kernel<CIN, HIN, STRIDE>), dim3((unsigned)blocks), dim3(256),
-                     lds_floats * 4, st, a);
+  if (v2)
+    hipLaunchKernelGGL((conv3x3_wgrad2_kernel<CIN, HIN, STRIDE>), dim3((unsigned)blocks), dim3(256), lds_floats * 4,
+                       st, a);
+  else
+    hipLaunchKernelGGL((conv3x3_wgrad_kernel<CIN, HIN, STRIDE>), dim3((unsigned)blocks), dim3(256), lds_floats * 4,
+                       st, a);
   DRQ_LAUNCH_CHECK();
   hipLaunchKernelGGL((conv3x3_wgrad_reduce_kernel<CIN, G::SMALL>), dim3(G::PART / 64), dim3(1024), 0, st,
                      (const float*)ws, (int)blocks, dw, db);
@@ -486,7 +725,10 @@ int drq_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, int
                       int stride, long dy_bs, long dy_cs, long dy_rs, long dy_off, float* ws, size_t ws_bytes,
                       hipStream_t st) {
   if (!x || !dy || !dw || !db || !ws || nb <= 0) return DRQ_EARG;
-  WgradArgs a{x, dy, dy_bs, dy_cs, dy_rs, dy_off, nullptr, nb};
+  const size_t xb = (size_t)nb * cin * hin * hin * 4;
+  const size_t dyb = (size_t)nb * dy_bs * 4;
+  if (xb >= (1ull << 31) || dyb >= (1ull << 31) || dy_off < 0 || dy_bs <= 0) return DRQ_EARG;
+  WgradArgs a{x, dy, dy_bs, dy_cs, dy_rs, dy_off, nullptr, (unsigned)xb, (unsigned)dyb, nb};
   if (cin == 9 && hin == 84 && stride == 2) return launch_wgrad<9, 84, 2>(a, dw, db, ws, ws_bytes, st);
   if (cin == 32 && stride == 1) {
     if (hin == 41) return launch_wgrad<32, 41, 1>(a, dw, db, ws, ws_bytes, st);
