@@ -553,6 +553,197 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad2_kernel(WgradArgs a) {
   }
 }
 
+// ---- wgrad v3 (stride 1, 32 input channels): wave-private ROLLING tile.  Consecutive output rows of a sample
+// share two of their three input rows, so the wave keeps a ring of 4 input rows and a double-buffered dY row in
+// LDS and fetches only ONE new input row + ONE dY row per output row (22 instead of 44 load / LDS-write
+// instructions).  Those are spread over the k-steps of the current row's MFMA loop (loads early, LDS writes
+// 7 steps later, into the ring slot / dY buffer the loop does not read), so staging hides under the MFMAs
+// although the wave is alone on its SIMD.  Disabled loads are sent out of range of the buffer descriptor
+// instead of being branched around (branches would force vmcnt(0) waits).
+template <int HIN>
+__global__ __launch_bounds__(256, 1) void conv3x3_wgrad3_kernel(WgradArgs a) {
+  constexpr int CIN = 32;
+  using G = WgradGeom<CIN, HIN, 1>;
+  constexpr int HOUT = G::HOUT, KS = G::KS, XP = G::XP, DP = G::DP, NT = 9;
+  constexpr int XJ = G::XJ, DJ = G::DJ, XRPI = G::XRPI, DRPI = G::DRPI;
+  constexpr int RS = CIN * XP;            // floats per ring slot (one input row, all channels)
+  constexpr int DS = 32 * DP;             // floats per dY buffer
+  constexpr int WAVE = 4 * RS + 2 * DS + 128;     // + a 64-lane x 8-byte dump row for disabled stores
+  static_assert(KS >= 18, "staging schedule needs 18 k-steps");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  const int col = lane & 31;
+  const int half = lane >> 5;
+  float* ring = smem + wid * WAVE;
+  float* dyb = ring + 4 * RS;
+  float* dump = dyb + 2 * DS + 2 * lane;          // disabled LDS stores land here: no branch around a store,
+                                                  // so hipcc cannot sink the matching load behind a vmcnt(0)
+  for (int i = lane; i < WAVE; i += 64) ring[i] = 0.f;     // pad columns stay finite / zero
+
+  const int bbase = col * XP + half;      // B operand: X[pixel][ci]
+  const int abase = col * DP + half;      // A operand: dY[cout][pixel]
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;
+
+  const long units = (long)a.nb * HOUT;
+  const long nw = (long)gridDim.x * 4;
+  const long gw = (long)blockIdx.x * 4 + wid;
+  const long u0 = units * gw / nw, u1 = units * (gw + 1) / nw;
+
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
+  const int xr = lane / G::XPAIRS, xpr = lane - xr * G::XPAIRS;
+  const int dr = lane / G::DPAIRS, dpr = lane - dr * G::DPAIRS;
+  const bool xact = xr < XRPI, dact = dr < DRPI;
+  const int xg_lane = (xr * HIN * HIN + 2 * xpr) * 4;
+  const int dg_lane = (int)(dr * a.dy_cs + 2 * dpr) * 4;
+  const int xl_lane = xr * XP + 2 * xpr;
+  const int dl_lane = dr * DP + 2 * dpr;
+  const bool d_last_odd = (HOUT & 1) && dpr == G::DPAIRS - 1;
+  constexpr int OOB = 0x7ffffff0;
+  // Hand-placed staging loads (inline asm, invisible to hipcc's scheduler and waitcnt pass, which otherwise sinks
+  // every load next to its LDS store and waits for it at once).  Their completion is counted by hand below:
+  // loads and only loads are outstanding inside the k-step loop, vmcnt retires them in issue order.
+  typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+  const unsigned long xaddr = (unsigned long)a.x, daddr = (unsigned long)a.dy;
+  const u32x4v xsrd = {(unsigned)xaddr, (unsigned)(xaddr >> 32) & 0xffffu, a.x_bytes, 0x00020000u};
+  const u32x4v dsrd = {(unsigned)daddr, (unsigned)(daddr >> 32) & 0xffffu, a.dy_bytes, 0x00020000u};
+  // only the last piece of a row group is partial: two lane masks per operand instead of one per piece
+  // (eleven hoisted 64-bit masks per operand exhaust the SGPRs)
+  const bool okx_full = xact, okx_last = xact && (XJ - 1) * XRPI + xr < CIN;
+  const bool okd_full = dact, okd_last = dact && (DJ - 1) * DRPI + dr < 32;
+
+  // load piece j of input row `row` of sample b / of the dY row (b, oy); `on` is wave-uniform
+  // (piece offsets are folded into the per-lane offset with literal adds and soffset stays 0: a scalar offset
+  //  per piece costs one SGPR each, and under SGPR pressure hipcc moves the buffer descriptor to VGPRs and wraps
+  //  every load in a waterfall loop)
+  auto ld_x = [&](int j, int b, int row, bool on) {
+    const bool ok = on && (j == XJ - 1 ? okx_last : okx_full);
+    const int voff = ok ? ((b * CIN * HIN + row) * HIN) * 4 + xg_lane + j * (XRPI * HIN * HIN * 4) : OOB;
+    return __builtin_amdgcn_raw_buffer_load_b64(xrsrc, voff, 0, 0);
+  };
+  auto ld_x_asm = [&](u32x2& dst, int j, int b, int row, bool on) {
+    const bool ok = on && (j == XJ - 1 ? okx_last : okx_full);
+    const int voff = ok ? ((b * CIN * HIN + row) * HIN) * 4 + xg_lane + j * (XRPI * HIN * HIN * 4) : OOB;
+    asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(xsrd) : "memory");
+  };
+  auto st_x = [&](int j, int slot, u32x2 v, bool on) {
+    const bool ok = on && (j == XJ - 1 ? okx_last : okx_full);
+    *reinterpret_cast<u32x2*>(ok ? ring + slot * RS + j * XRPI * XP + xl_lane : dump) = v;
+  };
+  const int d_bs4 = (int)a.dy_bs * 4, d_rs4 = (int)a.dy_rs * 4, d_off4 = (int)a.dy_off * 4;
+  const int d_step = (int)a.dy_cs * 4 * DRPI;
+  auto ld_d = [&](int j, int b, int oy, bool on) {
+    const bool ok = on && (j == DJ - 1 ? okd_last : okd_full);
+    const int voff = ok ? d_off4 + b * d_bs4 + oy * d_rs4 + dg_lane + j * d_step : OOB;
+    return __builtin_amdgcn_raw_buffer_load_b64(drsrc, voff, 0, 0);
+  };
+  auto ld_d_asm = [&](u32x2& dst, int j, int b, int oy, bool on) {
+    const bool ok = on && (j == DJ - 1 ? okd_last : okd_full);
+    const int voff = ok ? d_off4 + b * d_bs4 + oy * d_rs4 + dg_lane + j * d_step : OOB;
+    asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(dsrd) : "memory");
+  };
+  auto st_d = [&](int j, int buf, u32x2 v, bool on) {
+    const bool ok = on && (j == DJ - 1 ? okd_last : okd_full);
+    if (d_last_odd) v[1] = 0u;            // column HOUT of an odd row pairs with the pad pixel: keep it zero
+    *reinterpret_cast<u32x2*>(ok ? dyb + buf * DS + j * DRPI * DP + dl_lane : dump) = v;
+  };
+  // (re)start of a sample: three input rows into ring slots 0..2 (not overlapped; once per sample and wave start)
+  auto prime_x = [&](int b, int oy) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      u32x2 t[XJ];
+#pragma unroll
+      for (int j = 0; j < XJ; ++j) t[j] = ld_x(j, b, oy + k, true);
+#pragma unroll
+      for (int j = 0; j < XJ; ++j) st_x(j, k, t[j], true);
+    }
+  };
+
+  int slot = 0, dbuf = 0;
+  if (u0 < u1) {
+    const int b = (int)(u0 / HOUT), oy = (int)(u0 - (long)b * HOUT);
+    prime_x(b, oy);
+    u32x2 t[DJ];
+#pragma unroll
+    for (int j = 0; j < DJ; ++j) t[j] = ld_d(j, b, oy, true);
+#pragma unroll
+    for (int j = 0; j < DJ; ++j) st_d(j, 0, t[j], true);
+  }
+  for (long u = u0; u < u1; ++u) {
+    const int b = (int)(u / HOUT), oy = (int)(u - (long)b * HOUT);
+    const bool has_next = u + 1 < u1;
+    const bool same = has_next && oy + 1 < HOUT;          // next row belongs to the same sample
+    const int nb = same ? b : b + 1, noy = same ? oy + 1 : 0;
+    const int wslot = (slot + 3) & 3;
+    const int rb0 = bbase + ((slot + 0) & 3) * RS, rb1 = bbase + ((slot + 1) & 3) * RS,
+              rb2 = bbase + ((slot + 2) & 3) * RS;
+    const float* da = dyb + dbuf * DS + abase;
+    u32x2 sx[XJ], sd[DJ];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      // ---- staging for the next unit: piece s of the input row and of the dY row is loaded in step s (s < 11)
+      // and written to LDS in step s+7; N = loads issued after the pair being retired
+      static_assert(XJ == DJ && XJ == 11, "hand-counted schedule assumes 11 pieces per row");
+      if (s < XJ) {
+        ld_x_asm(sx[s], s, b, oy + 3, same);
+        ld_d_asm(sd[s], s, nb, noy, has_next);
+      }
+      if (s >= 7 && s - 7 < XJ) {
+        constexpr int LAST = XJ - 1;                       // last step that issues loads
+        const int n_after = 2 * ((s < LAST ? s : LAST) - (s - 7));
+        switch (n_after) {                                 // s is a compile-time constant after unrolling
+          case 14: asm volatile("s_waitcnt vmcnt(14)" : "+v"(sx[s - 7]), "+v"(sd[s - 7])); break;
+          case 12: asm volatile("s_waitcnt vmcnt(12)" : "+v"(sx[s - 7]), "+v"(sd[s - 7])); break;
+          case 10: asm volatile("s_waitcnt vmcnt(10)" : "+v"(sx[s - 7]), "+v"(sd[s - 7])); break;
+          case 8: asm volatile("s_waitcnt vmcnt(8)" : "+v"(sx[s - 7]), "+v"(sd[s - 7])); break;
+          case 6: asm volatile("s_waitcnt vmcnt(6)" : "+v"(sx[s - 7]), "+v"(sd[s - 7])); break;
+          case 4: asm volatile("s_waitcnt vmcnt(4)" : "+v"(sx[s - 7]), "+v"(sd[s - 7])); break;
+          case 2: asm volatile("s_waitcnt vmcnt(2)" : "+v"(sx[s - 7]), "+v"(sd[s - 7])); break;
+          default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(sx[s - 7]), "+v"(sd[s - 7])); break;
+        }
+        st_x(s - 7, wslot, sx[s - 7], same);
+        st_d(s - 7, dbuf ^ 1, sd[s - 7], has_next);
+      }
+      // ---- the MFMAs of pixel pair s
+      const float av = da[2 * s];
+      bsum += av;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int rb = (t / 3) == 0 ? rb0 : ((t / 3) == 1 ? rb1 : rb2);
+        const float bv = ring[rb + (t % 3) + 2 * s];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+      }
+    }
+    if (has_next && !same) {
+      prime_x(nb, 0);
+      slot = 0;
+    } else {
+      slot = (slot + 1) & 3;
+    }
+    dbuf ^= 1;
+  }
+
+  // ---- reduce the 4 waves of the block through LDS, one partial record per block
+  __syncthreads();
+  float* red = smem;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wid * G::PART + t * 1024 + r * 64 + lane] = acc[t][r];
+  red[wid * G::PART + NT * 1024 + lane] = bsum;
+  __syncthreads();
+  float* out = a.part + (long)blockIdx.x * G::PART;
+  for (int i = threadIdx.x; i < G::PART; i += 256)
+    out[i] = (red[i] + red[G::PART + i]) + (red[2 * G::PART + i] + red[3 * G::PART + i]);
+}
+
 // Sums the per-block partial records in a fixed order and scatters to the canonical layouts.
 // Block = 64 record elements x 16 groups of partials (1024 threads).
 template <int CIN, bool SMALL>
@@ -662,6 +853,26 @@ int launch_wgrad(const WgradArgs& a0, float* dw, float* db, float* ws, size_t ws
                               hipFuncAttributeMaxDynamicSharedMemorySize, G2::LDS_FLOATS * 4);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
+  }
+  if constexpr (STRIDE == 1 && CIN == 32) {
+    if (wgrad_variant() == 1) {          // default: rolling-tile kernel
+      constexpr int wave3 = 4 * CIN * G::XP + 2 * 32 * G::DP + 128;
+      constexpr int lds3 = (4 * wave3 > 4 * G::PART) ? 4 * wave3 : 4 * G::PART;
+      static_assert(lds3 * 4 <= 160 * 1024, "rolling tile too large");
+      static bool attr3 = false;
+      if (!attr3) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wgrad3_kernel<HIN>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds3 * 4);
+        if (e != hipSuccess) return (int)e;
+        attr3 = true;
+      }
+      hipLaunchKernelGGL((conv3x3_wgrad3_kernel<HIN>), dim3((unsigned)blocks), dim3(256), lds3 * 4, st, a);
+      DRQ_LAUNCH_CHECK();
+      hipLaunchKernelGGL((conv3x3_wgrad_reduce_kernel<CIN, G::SMALL>), dim3(G::PART / 64), dim3(1024), 0, st,
+                         (const float*)ws, (int)blocks, dw, db);
+      DRQ_LAUNCH_CHECK();
+      return DRQ_OK;
+    }
   }
   if (v2)
     hipLaunchKernelGGL((conv3x3_wgrad2_kernel<CIN, HIN, STRIDE>), dim3((unsigned)blocks), dim3(256), lds_floats * 4,
