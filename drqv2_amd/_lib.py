@@ -42,6 +42,10 @@ PROTOTYPES = {
     "drq_conv3x3_wgrad": (I, [P, P, P, P, I, I, I, I, L, L, L, L, P, SZ, P]),
     "drq_conv3x3_wgrad_ws_bytes": (SZ, []),
     "drq_gemm_f32": (I, [P, L, I, P, L, I, P, L, I, I, I, I, L, L, L, P, L, I, P, I, L, I, I, I, P, SZ, P]),
+    "drq_gemm_batched_f32": (I, [I, P, L, I, P, L, I, P, L, I, I, I, P, I, P, I, P, I, I, I, P, SZ, P]),
+    "drq_qout_fwd": (I, [I, P, P, P, P, I, I, P]),
+    "drq_qout_bwd": (I, [I, P, P, P, P, P, P, I, I, P]),
+    "drq_ln_tanh_fwd_multi": (I, [I, P, I, P, P, P, P, P, P, I, I, P]),
     "drq_ln_tanh_fwd": (I, [P, I, P, P, P, I, P, P, I, I, P]),
     "drq_ln_tanh_fwd2": (I, [P, P, I, P, P, P, P, P, I, P, I, P, P, P, P, I, I, P]),
     "drq_ln_tanh_bwd": (I, [P, I, P, I, P, I, P, P, P, P, P, P, P, I, I, P]),

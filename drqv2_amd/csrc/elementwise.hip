@@ -398,6 +398,86 @@ __global__ void tanh_kernel(const float* __restrict__ x, float* __restrict__ y, 
     y[i] = tanhf(x[i]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Output layer of a Q head (nn.Linear(hidden,1), drqv2.py:106,111): a GEMM with N = 1 is a row dot
+// product; forward = one wave per row, backward = dgrad (outer product, ReLU-masked), wgrad and bias
+// gradient in ONE pass over the hidden activations.  Up to 8 (net, head) problems per launch.
+// ------------------------------------------------------------------------------------------------
+struct QOutArgs {
+  const float* h[8];    // [B][H] hidden activations (post-ReLU)
+  const float* w[8];    // [H]
+  const float* b[8];    // [1]
+  float* q[8];          // [B]
+  int B, H;
+};
+
+__global__ void qout_fwd_kernel(QOutArgs a) {
+  const int z = blockIdx.y;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= a.B) return;
+  const float* h = a.h[z] + (long)row * a.H;
+  const float* w = a.w[z];
+  float s0 = 0.f, s1 = 0.f;
+  int i = lane;
+  for (; i + 64 < a.H; i += 128) {
+    s0 = __fmaf_rn(h[i], w[i], s0);
+    s1 = __fmaf_rn(h[i + 64], w[i + 64], s1);
+  }
+  if (i < a.H) s0 = __fmaf_rn(h[i], w[i], s0);
+  const float s = wave_sum(s0 + s1);
+  if (lane == 0) a.q[z][row] = s + a.b[z][0];
+}
+
+struct QOutBwdArgs {
+  const float* dq[8];   // [B]
+  const float* h[8];    // [B][H]
+  const float* w[8];    // [H]
+  float* dh[8];         // [B][H] = dq*w masked by h > 0
+  float* dw[8];         // [H] or null
+  float* db[8];         // [1] or null
+  int B, H;
+};
+
+__global__ __launch_bounds__(1024) void qout_bwd_kernel(QOutBwdArgs a) {
+  __shared__ float s[16][64];
+  __shared__ float sb[16];
+  const int z = blockIdx.y;
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + c;
+  const float* dq = a.dq[z];
+  const float* h = a.h[z];
+  float* dh = a.dh[z];
+  const float wn = n < a.H ? a.w[z][n] : 0.f;
+  float acc = 0.f, bacc = 0.f;
+  for (int m = rg; m < a.B; m += 16) {
+    const float d = dq[m];
+    bacc += d;
+    if (n < a.H) {
+      const float hv = h[(long)m * a.H + n];
+      dh[(long)m * a.H + n] = hv > 0.f ? d * wn : 0.f;
+      acc = __fmaf_rn(d, hv, acc);
+    }
+  }
+  s[rg][c] = acc;
+  if (c == 0) sb[rg] = bacc;
+  __syncthreads();
+  if (rg == 0) {
+    if (a.dw[z] && n < a.H) {
+      float t = 0.f;
+#pragma unroll
+      for (int g2 = 0; g2 < 16; ++g2) t += s[g2][c];
+      a.dw[z][n] = t;
+    }
+    if (a.db[z] && blockIdx.x == 0 && c == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int g2 = 0; g2 < 16; ++g2) t += sb[g2];
+      a.db[z][0] = t;
+    }
+  }
+}
+
 inline unsigned grid_for(long n, int block = 256) {
   long g = (n + block - 1) / block;
   const long cap = 8L * drq_num_cus();
@@ -464,6 +544,57 @@ int drq_ln_tanh_bwd(const float* dh0, int ld0, const float* dh1, int ld1, const 
   hipLaunchKernelGGL(ln_tanh_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, a);
   DRQ_LAUNCH_CHECK();
   hipLaunchKernelGGL(ln_param_grad_kernel, dim3(F), dim3(256), 0, st, (const float*)dln, xhat, dgamma, dbeta, rows, F);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
+// nz (<= 8) Q-head output layers in one launch; host arrays of device pointers
+int drq_qout_fwd(int nz, const float* const* h, const float* const* w, const float* const* b, float* const* q, int B,
+                 int H, hipStream_t st) {
+  if (nz <= 0 || nz > 8 || !h || !w || !b || !q || B <= 0 || H <= 0) return DRQ_EARG;
+  QOutArgs a{};
+  for (int z = 0; z < nz; ++z) {
+    if (!h[z] || !w[z] || !b[z] || !q[z]) return DRQ_EARG;
+    a.h[z] = h[z]; a.w[z] = w[z]; a.b[z] = b[z]; a.q[z] = q[z];
+  }
+  a.B = B; a.H = H;
+  hipLaunchKernelGGL(qout_fwd_kernel, dim3((B + 3) / 4, nz), dim3(256), 0, st, a);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
+// dh = (dq w^T) * (h > 0);  dw = dq^T h, db = sum dq when the dw/db arrays are given
+int drq_qout_bwd(int nz, const float* const* dq, const float* const* h, const float* const* w, float* const* dh,
+                 float* const* dw, float* const* db, int B, int H, hipStream_t st) {
+  if (nz <= 0 || nz > 8 || !dq || !h || !w || !dh || B <= 0 || H <= 0) return DRQ_EARG;
+  QOutBwdArgs a{};
+  for (int z = 0; z < nz; ++z) {
+    if (!dq[z] || !h[z] || !w[z] || !dh[z]) return DRQ_EARG;
+    a.dq[z] = dq[z]; a.h[z] = h[z]; a.w[z] = w[z]; a.dh[z] = dh[z];
+    a.dw[z] = dw ? dw[z] : nullptr;
+    a.db[z] = db ? db[z] : nullptr;
+  }
+  a.B = B; a.H = H;
+  hipLaunchKernelGGL(qout_bwd_kernel, dim3((H + 63) / 64, nz), dim3(1024), 0, st, a);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
+// n (<= 4) LayerNorm+tanh problems of the same (rows, F) in one launch
+int drq_ln_tanh_fwd_multi(int n, const float* const* z, int ldz, const float* const* gamma, const float* const* beta,
+                          float* const* out, const int* ldo, float* const* xhat, float* const* rstd, int rows, int F,
+                          hipStream_t st) {
+  if (n <= 0 || n > 4 || !z || !gamma || !beta || !out || !ldo || rows <= 0 || F <= 0 || F > 256) return DRQ_EARG;
+  LnArgs a{};
+  for (int i = 0; i < n; ++i) {
+    if (!z[i] || !gamma[i] || !beta[i] || !out[i]) return DRQ_EARG;
+    a.z[i] = z[i]; a.gamma[i] = gamma[i]; a.beta[i] = beta[i]; a.out[i] = out[i];
+    a.xhat[i] = xhat ? xhat[i] : nullptr;
+    a.rstd[i] = rstd ? rstd[i] : nullptr;
+    a.ldz[i] = ldz; a.ldo[i] = ldo[i];
+  }
+  a.rows = rows; a.F = F;
+  hipLaunchKernelGGL(ln_tanh_fwd_kernel, dim3((rows + 3) / 4, n), dim3(256), 0, st, a);
   DRQ_LAUNCH_CHECK();
   return DRQ_OK;
 }

@@ -19,21 +19,22 @@ namespace {
 constexpr int BK = 32;
 constexpr int PK = 34;
 
+constexpr int MAXB = 8;      // problems per launch (same shape, independent pointers)
+
 struct Epilogue {
-  const float* bias;    // [N] (+ batch stride) or null
-  const float* aux;     // relu mask source [M][ldaux] or null : v = aux>0 ? v : 0
-  long bias_bs, aux_bs;
+  const float* bias[MAXB];   // [N] or null
+  const float* aux[MAXB];    // relu mask source [M][ldaux] or null : v = aux>0 ? v : 0
+  float* rowsum[MAXB];       // [M] or null: sum_k A(m,k) (bias gradient of a wgrad GEMM); needs !A_KC, splitk == 1
   int ldaux;
   int relu;
-  int scatter_hw;       // >0: C index = padded NCHW scatter (trunk dgrad -> conv4 grad layout, pad 2)
+  int scatter_hw;            // >0: C index = padded NCHW scatter (trunk dgrad -> conv4 grad layout, pad 2)
 };
 
 struct GemmArgs {
-  const float* A;
-  const float* B;
-  float* C;
+  const float* A[MAXB];
+  const float* B[MAXB];
+  float* C[MAXB];
   long lda, ldb, ldc;
-  long a_bs, b_bs, c_bs;     // batch strides (elements)
   int M, N, K;
   int nbatch, splitk, kchunk;
   float* part;               // split-K partials [nbatch*splitk][M][N]
@@ -42,10 +43,10 @@ struct GemmArgs {
 
 __device__ __forceinline__ void epilogue_store(const GemmArgs& g, int batch, int m, int n, float v) {
   const Epilogue& e = g.ep;
-  if (e.bias) v += e.bias[batch * e.bias_bs + n];
+  if (e.bias[batch]) v += e.bias[batch][n];
   if (e.relu) v = v > 0.f ? v : 0.f;
-  if (e.aux) v = (e.aux[batch * e.aux_bs + (long)m * e.ldaux + n] > 0.f) ? v : 0.f;
-  float* c = g.C + batch * g.c_bs;
+  if (e.aux[batch]) v = (e.aux[batch][(long)m * e.ldaux + n] > 0.f) ? v : 0.f;
+  float* c = g.C[batch];
   if (e.scatter_hw > 0) {
     const int hw = e.scatter_hw, hp = hw + 4;
     const int ch = n / (hw * hw);
@@ -119,6 +120,21 @@ __device__ __forceinline__ void store_tile(float* S, const float (&reg)[BR * BK 
   }
 }
 
+// masked sum of this thread's staged A values (row-contiguous layout only): piece of sum_k A(m,k)
+template <int BR>
+__device__ __forceinline__ float tile_rowsum(const float (&reg)[BR * BK / 256], int row0, int rows, int k0, int kend,
+                                             int tid) {
+  const int r = tid % BR, kk0 = tid / BR;
+  constexpr int KSTEP = 256 / BR;
+  float s = 0.f;
+  if (row0 + r < rows) {
+#pragma unroll
+    for (int p = 0; p < BR * BK / 256; ++p)
+      if (k0 + kk0 + p * KSTEP < kend) s += reg[p];
+  }
+  return s;
+}
+
 template <int TM, int TN, bool A_KC, bool B_KC, bool V4>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
@@ -137,8 +153,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int kbeg = ks * g.kchunk;
   const int kend = min(g.K, kbeg + g.kchunk);
-  const float* A = g.A + batch * g.a_bs;
-  const float* B = g.B + batch * g.b_bs;
+  const float* A = g.A[batch];
+  const float* B = g.B[batch];
 
   float ra[D][RA], rb[D][RB];
 
@@ -158,8 +174,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     load_tile<BM, A_KC, V4>(A, g.lda, m0, g.M, kbeg + tc * BK, kend, fa, tid);
     load_tile<BN, B_KC, V4>(B, g.ldb, n0, g.N, kbeg + tc * BK, kend, fb, tid);
   };
+  // fused bias gradient of a wgrad GEMM: the workgroups of the first column tile also sum their A rows over k
+  bool do_rs = false;
+  if constexpr (!A_KC) do_rs = g.ep.rowsum[batch] != nullptr && blockIdx.x == 0;
+  float rs = 0.f;
   if (nsteps > 0) {
     fetch(0, ra[0], rb[0]);
+    if constexpr (!A_KC)
+      if (do_rs) rs += tile_rowsum<BM>(ra[0], m0, g.M, kbeg, kend, tid);
     store_tile<BM, A_KC, V4>(As[0], ra[0], m0, g.M, kbeg, kend, tid);
     store_tile<BN, B_KC, V4>(Bs[0], rb[0], n0, g.N, kbeg, kend, tid);
 #pragma unroll
@@ -190,6 +212,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+    if constexpr (!A_KC)
+      if (do_rs) rs += tile_rowsum<BM>(ra[(s + 1) % D], m0, g.M, kbeg + (t + 1) * BK, kend, tid);
     store_tile<BM, A_KC, V4>(As[(s + 1) & 1], ra[(s + 1) % D], m0, g.M, kbeg + (t + 1) * BK, kend, tid);
     store_tile<BN, B_KC, V4>(Bs[(s + 1) & 1], rb[(s + 1) % D], n0, g.N, kbeg + (t + 1) * BK, kend, tid);
     fetch(t + 1 + D, ra[(s + 1) % D], rb[(s + 1) % D]);
@@ -208,6 +232,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   if constexpr (D == 4) {
     if (t0 + 1 < nsteps) step(t0 + 1, std::integral_constant<int, 1>{});
     if (t0 + 2 < nsteps) step(t0 + 2, std::integral_constant<int, 2>{});
+  }
+
+  if constexpr (!A_KC) {
+    if (do_rs) {           // 256/BM threads hold pieces of each row sum: combine in a fixed order through LDS
+      float* red = As[0];
+      red[tid] = rs;
+      __syncthreads();
+      if (tid < BM && m0 + tid < g.M) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 256 / BM; ++q) t += red[tid + q * BM];
+        g.ep.rowsum[batch][m0 + tid] = t;
+      }
+    }
   }
 
   // ---- store: C/D layout col = lane&15, row = (lane>>4)*4 + reg.  Two phases so that every bias / mask
@@ -232,8 +270,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   float av[TM][TN][4];
 #pragma unroll
   for (int j = 0; j < TN; ++j) bv[j] = 0.f;
-  if (e.bias) {
-    const float* bp = e.bias + batch * e.bias_bs;
+  if (e.bias[batch]) {
+    const float* bp = e.bias[batch];
 #pragma unroll
     for (int j = 0; j < TN; ++j) bv[j] = bp[min(ncol0 + j * 16, g.N - 1)];
   }
@@ -243,8 +281,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) av[i][j][r] = 1.f;
-  if (e.aux) {
-    const float* ap = e.aux + batch * e.aux_bs;
+  if (e.aux[batch]) {
+    const float* ap = e.aux[batch];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -253,7 +291,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         for (int r = 0; r < 4; ++r)
           av[i][j][r] = ap[(long)min(mrow0 + i * 16 + r, g.M - 1) * e.ldaux + min(ncol0 + j * 16, g.N - 1)];
   }
-  float* c = g.C + batch * g.c_bs;
+  float* c = g.C[batch];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -329,17 +367,21 @@ int dispatch(const GemmArgs& g, int a_kc, int b_kc, bool v4, hipStream_t st) {
 
 extern "C" {
 
-// See include/drqv2_hip.h.  tile: 1 = 32x32 block tile, 2 = 64x64, 0 = choose.  splitk: 0 = choose.
-int drq_gemm_f32(const float* A, long lda, int a_kc, const float* B, long ldb, int b_kc, float* C, long ldc,
-                 int M, int N, int K, int nbatch, long a_bs, long b_bs, long c_bs, const float* bias, long bias_bs,
-                 int relu, const float* aux, int ldaux, long aux_bs, int scatter_hw, int tile, int splitk,
-                 float* ws, size_t ws_bytes, hipStream_t st) {
-  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || nbatch <= 0) return DRQ_EARG;
+// See include/drqv2_hip.h.  Host arrays of nbatch (<= 8) device pointers; bias/aux/rowsum arrays may be null.
+int drq_gemm_batched_f32(int nbatch, const float* const* A, long lda, int a_kc, const float* const* B, long ldb,
+                         int b_kc, float* const* C, long ldc, int M, int N, int K, const float* const* bias, int relu,
+                         const float* const* aux, int ldaux, float* const* rowsum, int scatter_hw, int tile,
+                         int splitk, float* ws, size_t ws_bytes, hipStream_t st) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || nbatch <= 0 || nbatch > MAXB) return DRQ_EARG;
+  for (int b = 0; b < nbatch; ++b)
+    if (!A[b] || !B[b] || !C[b]) return DRQ_EARG;
+  if (rowsum && a_kc) return DRQ_EARG;
   const int cus = drq_num_cus();
   const long t_big = (long)((M + 63) / 64) * ((N + 63) / 64) * nbatch;
   const long t_small = (long)((M + 31) / 32) * ((N + 31) / 32) * nbatch;
   if (tile == 0) tile = (t_big >= 2L * cus) ? 2 : 1;
   const long tiles = tile == 2 ? t_big : t_small;
+  if (rowsum) splitk = 1;
   if (splitk == 0) {
     splitk = 1;
     if (tiles < 2L * cus && K >= 256) {
@@ -352,17 +394,40 @@ int drq_gemm_f32(const float* A, long lda, int a_kc, const float* B, long ldb, i
   int kchunk = ((K + splitk - 1) / splitk + BK - 1) / BK * BK;
   splitk = (K + kchunk - 1) / kchunk;
   if (splitk > 1 && (!ws || (size_t)nbatch * splitk * M * N * sizeof(float) > ws_bytes)) return DRQ_EWS;
-  GemmArgs g;
-  g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
-  g.a_bs = a_bs; g.b_bs = b_bs; g.c_bs = c_bs; g.M = M; g.N = N; g.K = K;
-  g.nbatch = nbatch; g.splitk = splitk; g.kchunk = kchunk; g.part = ws;
-  g.ep = Epilogue{bias, aux, bias_bs, aux_bs, ldaux, relu, scatter_hw};
+  GemmArgs g{};
   auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
-  bool v4 = (K % 4 == 0);
-  if (a_kc) v4 = v4 && al16(A) && lda % 4 == 0 && a_bs % 4 == 0;
-  if (b_kc) v4 = v4 && al16(B) && ldb % 4 == 0 && b_bs % 4 == 0;
-  if (!a_kc && !b_kc) v4 = false;
+  bool v4 = (K % 4 == 0) && (a_kc || b_kc);
+  if (a_kc) v4 = v4 && lda % 4 == 0;
+  if (b_kc) v4 = v4 && ldb % 4 == 0;
+  for (int b = 0; b < nbatch; ++b) {
+    g.A[b] = A[b]; g.B[b] = B[b]; g.C[b] = C[b];
+    g.ep.bias[b] = bias ? bias[b] : nullptr;
+    g.ep.aux[b] = aux ? aux[b] : nullptr;
+    g.ep.rowsum[b] = rowsum ? rowsum[b] : nullptr;
+    if (a_kc) v4 = v4 && al16(A[b]);
+    if (b_kc) v4 = v4 && al16(B[b]);
+  }
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+  g.nbatch = nbatch; g.splitk = splitk; g.kchunk = kchunk; g.part = ws;
+  g.ep.ldaux = ldaux; g.ep.relu = relu; g.ep.scatter_hw = scatter_hw;
   return tile == 2 ? dispatch<2, 2>(g, a_kc, b_kc, v4, st) : dispatch<1, 1>(g, a_kc, b_kc, v4, st);
+}
+
+// strided-batch form of the same call
+int drq_gemm_f32(const float* A, long lda, int a_kc, const float* B, long ldb, int b_kc, float* C, long ldc,
+                 int M, int N, int K, int nbatch, long a_bs, long b_bs, long c_bs, const float* bias, long bias_bs,
+                 int relu, const float* aux, int ldaux, long aux_bs, int scatter_hw, int tile, int splitk,
+                 float* ws, size_t ws_bytes, hipStream_t st) {
+  if (!A || !B || !C || nbatch <= 0 || nbatch > MAXB) return DRQ_EARG;
+  const float *Ap[MAXB], *Bp[MAXB], *bp[MAXB], *xp[MAXB];
+  float* Cp[MAXB];
+  for (int b = 0; b < nbatch; ++b) {
+    Ap[b] = A + b * a_bs; Bp[b] = B + b * b_bs; Cp[b] = C + b * c_bs;
+    bp[b] = bias ? bias + b * bias_bs : nullptr;
+    xp[b] = aux ? aux + b * aux_bs : nullptr;
+  }
+  return drq_gemm_batched_f32(nbatch, Ap, lda, a_kc, Bp, ldb, b_kc, Cp, ldc, M, N, K, bias ? bp : nullptr, relu,
+                              aux ? xp : nullptr, ldaux, nullptr, scatter_hw, tile, splitk, ws, ws_bytes, st);
 }
 
 }  // extern "C"

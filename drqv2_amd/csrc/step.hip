@@ -77,7 +77,7 @@ enum {
   W_MU_O = DRQ_WS_MU_O, W_DY4 = DRQ_WS_DY4, W_DY3 = DRQ_WS_DY3, W_DY2 = DRQ_WS_DY2, W_DY1 = DRQ_WS_DY1,
   W_DZ_C = DRQ_WS_DZ_C, W_DZ_A = DRQ_WS_DZ_A, W_HA_C2 = DRQ_WS_HA_C2,
   W_XHAT_C = DRQ_WS_NBUF_PUBLIC, W_RSTD_C, W_XHAT_A, W_RSTD_A, W_Z_C2,
-  W_PN1, W_PN2, W_PN3, W_PO1, W_PO2, W_PO3,       // policy activations (next / obs)
+  W_HROWS, W_P1, W_P2, W_P3, W_Z4,                // actor trunk output / policy activations over 2B rows (obs, next)
   W_T1, W_T2,                                     // target-Q hidden activations, reused by the actor step
   W_C1, W_C2,                                     // critic-Q hidden activations
   W_DC2, W_DC1, W_DHA, W_DLN, W_DPRE, W_DP2, W_DP1, W_DH_A, W_DA,
@@ -119,12 +119,11 @@ WsLayout ws_layout(int B, int C, int A, int F, int H) {
   take(W_XHAT_A, (long)B * F);
   take(W_RSTD_A, B);
   take(W_Z_C2, (long)B * F);
-  take(W_PN1, (long)B * H);
-  take(W_PN2, (long)B * H);
-  take(W_PN3, (long)B * A);
-  take(W_PO1, (long)B * H);
-  take(W_PO2, (long)B * H);
-  take(W_PO3, (long)B * A);
+  take(W_HROWS, 2L * B * F);
+  take(W_P1, 2L * B * H);
+  take(W_P2, 2L * B * H);
+  take(W_P3, 2L * B * A);
+  take(W_Z4, 4L * B * F);
   take(W_T1, 2L * B * H);
   take(W_T2, 2L * B * H);
   take(W_C1, 2L * B * H);
@@ -163,31 +162,28 @@ struct Ctx {
   float* gemm_ws() const { return ws(W_GEMM_WS); }
   size_t gemm_ws_bytes() const { return (size_t)16 * 1024 * 1024 * sizeof(float); }
 
-  // y[b] = act(x W^T + bias), batched over nb heads with strides between heads
-  int linear_fwd(const float* x, long ldx, long x_bs, const float* w, long w_bs, const float* bias, long bias_bs,
-                 float* y, long ldy, long y_bs, int M, int N, int K, int nb, int relu) const {
-    return drq_gemm_f32(x, ldx, 1, w, K, 1, y, ldy, M, N, K, nb, x_bs, w_bs, y_bs, bias, bias_bs, relu, nullptr, 0,
-                        0, 0, 0, 0, gemm_ws(), gemm_ws_bytes(), st);
+  // n problems  y_i = act(x_i W_i^T + b_i)
+  int fwd(int n, const float* const* x, long ldx, const float* const* w, const float* const* b, float* const* y,
+          long ldy, int M, int N, int K, int relu) const {
+    return drq_gemm_batched_f32(n, x, ldx, 1, w, K, 1, y, ldy, M, N, K, b, relu, nullptr, 0, nullptr, 0, 0, 0,
+                                gemm_ws(), gemm_ws_bytes(), st);
   }
-  // dx[b] = (dy W) * (mask > 0)
-  int linear_dgrad(const float* dy, long lddy, long dy_bs, const float* w, long ldw, long w_bs, float* dx, long lddx,
-                   long dx_bs, int M, int Nout, int K, int nb, const float* mask, int ldmask, long mask_bs) const {
-    return drq_gemm_f32(dy, lddy, 1, w, ldw, 0, dx, lddx, M, Nout, K, nb, dy_bs, w_bs, dx_bs, nullptr, 0, 0, mask,
-                        ldmask, mask_bs, 0, 0, 0, gemm_ws(), gemm_ws_bytes(), st);
+  // n problems  dx_i = (dy_i W_i) * (mask_i > 0);  W_i is [K][ldw] row-major, the first Nout columns are used
+  int dgrad(int n, const float* const* dy, long lddy, const float* const* w, long ldw, float* const* dx, long lddx,
+            int M, int Nout, int K, const float* const* mask, int ldmask) const {
+    return drq_gemm_batched_f32(n, dy, lddy, 1, w, ldw, 0, dx, lddx, M, Nout, K, nullptr, 0, mask, ldmask, nullptr, 0,
+                                0, 0, gemm_ws(), gemm_ws_bytes(), st);
   }
-  // dW[b] = dy^T x  ([N][K] row-major), db[b] = colsum(dy)
-  int linear_wgrad(const float* dy, long lddy, long dy_bs, const float* x, long ldx, long x_bs, float* dw, long dw_bs,
-                   float* db, long db_bs, int Brows, int N, int K, int nb) const {
-    CK(drq_gemm_f32(dy, lddy, 0, x, ldx, 0, dw, K, N, K, Brows, nb, dy_bs, x_bs, dw_bs, nullptr, 0, 0, nullptr, 0, 0,
-                    0, 0, 0, gemm_ws(), gemm_ws_bytes(), st));
-    return drq_colsum(dy, lddy, dy_bs, db, db_bs, Brows, N, nb, st);
+  // n problems  dW_i = dy_i^T x_i ([N][K] row-major), db_i = column sums of dy_i (fused)
+  int wgrad(int n, const float* const* dy, long lddy, const float* const* x, long ldx, float* const* dw,
+            float* const* db, int Brows, int N, int K) const {
+    return drq_gemm_batched_f32(n, dy, lddy, 0, x, ldx, 0, dw, K, N, K, Brows, nullptr, 0, nullptr, 0, db, 0, 0, 0,
+                                gemm_ws(), gemm_ws_bytes(), st);
   }
 };
 
 int encoder_forward(const Ctx& c, const float* x, int nb, float* a1, float* a2, float* a3, float* a4) {
   const ParamLayout& P = c.P;
-  const int C = c.s->C;
-  (void)C;
   float* outs[4] = {a1, a2, a3, a4};
   const float* in = x;
   for (int l = 0; l < 4; ++l) {
@@ -199,24 +195,44 @@ int encoder_forward(const Ctx& c, const float* x, int nb, float* a1, float* a2, 
   return 0;
 }
 
-// Q(h,a) for both heads of `net` on rows of `ha` -> q[2][B]; hidden activations into h1,h2 [2][B][H]
-int q_forward(const Ctx& c, const HeadOff& net, const float* ha, float* h1, float* h2, float* q) {
+// policy MLP (drqv2.py:77-81) on `rows` rows of h -> pre-tanh output p3
+int policy_forward(const Ctx& c, const float* h, int rows, float* p1, float* p2, float* p3) {
   const DrqStep* s = c.s;
-  const int B = s->B, H = s->H, FA = s->F + s->A;
-  const long wbs = net.w[1][0] - net.w[0][0];   // distance between the Q1 and Q2 parameter blocks
-  CK(c.linear_fwd(ha, FA, 0, c.p(net.w[0][0]), wbs, c.p(net.b[0][0]), wbs, h1, H, (long)B * H, B, H, FA, 2, 1));
-  CK(c.linear_fwd(h1, H, (long)B * H, c.p(net.w[0][1]), wbs, c.p(net.b[0][1]), wbs, h2, H, (long)B * H, B, H, H, 2, 1));
-  CK(c.linear_fwd(h2, H, (long)B * H, c.p(net.w[0][2]), wbs, c.p(net.b[0][2]), wbs, q, 1, B, B, 1, H, 2, 0));
+  const HeadOff& a = c.P.actor;
+  const int H = s->H, F = s->F, A = s->A;
+  const float *x0[1] = {h}, *x1[1] = {p1}, *x2[1] = {p2};
+  const float *w0[1] = {c.p(a.w[0][0])}, *w1[1] = {c.p(a.w[0][1])}, *w2[1] = {c.p(a.w[0][2])};
+  const float *b0[1] = {c.p(a.b[0][0])}, *b1[1] = {c.p(a.b[0][1])}, *b2[1] = {c.p(a.b[0][2])};
+  float *y0[1] = {p1}, *y1[1] = {p2}, *y2[1] = {p3};
+  CK(c.fwd(1, x0, F, w0, b0, y0, H, rows, H, F, 1));
+  CK(c.fwd(1, x1, H, w1, b1, y1, H, rows, H, H, 1));
+  CK(c.fwd(1, x2, H, w2, b2, y2, A, rows, A, H, 0));
   return 0;
 }
 
-int policy_forward(const Ctx& c, const float* h, float* p1, float* p2, float* p3) {
+// Twin-Q forward for `nn` (net, input) pairs at once: 2*nn problems per layer (drqv2.py:103-111,117-119)
+int q_forward(const Ctx& c, int nn, const HeadOff* const* nets, const float* const* ha, float* const* h1,
+              float* const* h2, float* const* q) {
   const DrqStep* s = c.s;
-  const HeadOff& a = c.P.actor;
-  const int B = s->B, H = s->H, F = s->F, A = s->A;
-  CK(c.linear_fwd(h, F, 0, c.p(a.w[0][0]), 0, c.p(a.b[0][0]), 0, p1, H, 0, B, H, F, 1, 1));
-  CK(c.linear_fwd(p1, H, 0, c.p(a.w[0][1]), 0, c.p(a.b[0][1]), 0, p2, H, 0, B, H, H, 1, 1));
-  CK(c.linear_fwd(p2, H, 0, c.p(a.w[0][2]), 0, c.p(a.b[0][2]), 0, p3, A, 0, B, A, H, 1, 0));
+  const int B = s->B, H = s->H, FA = s->F + s->A;
+  const long BH = (long)B * H;
+  const float *x[8], *w[8], *b[8], *hh1[8], *hh2[8];
+  float *y1[8], *y2[8], *qq[8];
+  for (int l = 0; l < 3; ++l) {
+    for (int i = 0; i < nn; ++i)
+      for (int h = 0; h < 2; ++h) {
+        const int z = 2 * i + h;
+        w[z] = c.p(nets[i]->w[h][l]);
+        b[z] = c.p(nets[i]->b[h][l]);
+        x[z] = ha[i];
+        y1[z] = h1[i] + h * BH; hh1[z] = y1[z];
+        y2[z] = h2[i] + h * BH; hh2[z] = y2[z];
+        qq[z] = q[i] + h * B;
+      }
+    if (l == 0) CK(c.fwd(2 * nn, x, FA, w, b, y1, H, B, H, FA, 1));
+    if (l == 1) CK(c.fwd(2 * nn, hh1, H, w, b, y2, H, B, H, H, 1));
+    if (l == 2) CK(drq_qout_fwd(2 * nn, hh2, w, b, qq, B, H, c.st));
+  }
   return 0;
 }
 
@@ -230,6 +246,8 @@ int phase_critic(const Ctx& c) {
   float* feat = c.ws(W_FEAT);
   float* feat_obs = feat;
   float* feat_next = feat + (long)B * R;
+  const HeadOff &cr = P.critic, &ac = P.actor, &tg = P.target;
+  const long BH = (long)B * H;
 
   // aug (drqv2.py:241-242) + /255-0.5 (:64); rows [0,B) = obs, [B,2B) = next_obs
   CK(drq_aug_fwd(s->obs, s->shift_obs, s->base_grid, aug, B, C, 84, 4, 1, st));
@@ -237,50 +255,78 @@ int phase_critic(const Ctx& c) {
   // encoder on both views in one pass (:244-246)
   CK(encoder_forward(c, aug, 2 * B, c.ws(W_ACT1), c.ws(W_ACT2), c.ws(W_ACT3), feat));
 
-  // trunks: next -> (actor, target); obs -> (critic, actor)
-  CK(c.linear_fwd(feat_next, R, 0, c.p(P.actor.trunk_w), P.target.trunk_w - P.actor.trunk_w, c.p(P.actor.trunk_b),
-                  P.target.trunk_b - P.actor.trunk_b, c.ws(W_Z_NEXT), 2 * F, F, B, F, (int)R, 2, 0));
-  CK(c.linear_fwd(feat_obs, R, 0, c.p(P.critic.trunk_w), P.actor.trunk_w - P.critic.trunk_w, c.p(P.critic.trunk_b),
-                  P.actor.trunk_b - P.critic.trunk_b, c.ws(W_Z_OBS), 2 * F, F, B, F, (int)R, 2, 0));
-  CK(drq_ln_tanh_fwd2(c.ws(W_Z_NEXT), c.ws(W_Z_NEXT) + F, 2 * F, c.p(P.actor.ln_g), c.p(P.actor.ln_b),
-                      c.p(P.target.ln_g), c.p(P.target.ln_b), c.ws(W_H_AN), F, c.ws(W_HA_T), FA, nullptr, nullptr,
-                      nullptr, nullptr, B, F, st));
-  CK(drq_ln_tanh_fwd2(c.ws(W_Z_OBS), c.ws(W_Z_OBS) + F, 2 * F, c.p(P.critic.ln_g), c.p(P.critic.ln_b),
-                      c.p(P.actor.ln_g), c.p(P.actor.ln_b), c.ws(W_HA_C), FA, c.ws(W_H_AO), F, c.ws(W_XHAT_C),
-                      c.ws(W_RSTD_C), c.ws(W_XHAT_A), c.ws(W_RSTD_A), B, F, st));
+  // all four trunks in one launch: critic(obs), actor(obs), actor(next), target(next).  actor(obs) is needed
+  // only by the actor step; the actor's weights do not change before that, so it is evaluated here.
+  float* z4 = c.ws(W_Z4);
+  float* hrows = c.ws(W_HROWS);        // actor trunk outputs: rows [0,B) obs, [B,2B) next
+  {
+    const float* x[4] = {feat_obs, feat_obs, feat_next, feat_next};
+    const float* w[4] = {c.p(cr.trunk_w), c.p(ac.trunk_w), c.p(ac.trunk_w), c.p(tg.trunk_w)};
+    const float* b[4] = {c.p(cr.trunk_b), c.p(ac.trunk_b), c.p(ac.trunk_b), c.p(tg.trunk_b)};
+    float* y[4] = {z4, z4 + (long)B * F, z4 + 2L * B * F, z4 + 3L * B * F};
+    CK(c.fwd(4, x, R, w, b, y, F, B, F, (int)R, 0));
+    const float* zz[4] = {y[0], y[1], y[2], y[3]};
+    const float* gm[4] = {c.p(cr.ln_g), c.p(ac.ln_g), c.p(ac.ln_g), c.p(tg.ln_g)};
+    const float* bt[4] = {c.p(cr.ln_b), c.p(ac.ln_b), c.p(ac.ln_b), c.p(tg.ln_b)};
+    float* out[4] = {c.ws(W_HA_C), hrows, hrows + (long)B * F, c.ws(W_HA_T)};
+    const int ldo[4] = {FA, F, F, FA};
+    float* xh[4] = {c.ws(W_XHAT_C), c.ws(W_XHAT_A), nullptr, nullptr};
+    float* rs[4] = {c.ws(W_RSTD_C), c.ws(W_RSTD_A), nullptr, nullptr};
+    CK(drq_ln_tanh_fwd_multi(4, zz, F, gm, bt, out, ldo, xh, rs, B, F, st));
+  }
+  // policy MLP once on the 2B stacked rows
+  CK(policy_forward(c, hrows, 2 * B, c.ws(W_P1), c.ws(W_P2), c.ws(W_P3)));
 
-  // target: a' ~ TruncN(actor(next)), y = r + d*min Q_target(next, a')   (:180-186)
-  CK(policy_forward(c, c.ws(W_H_AN), c.ws(W_PN1), c.ws(W_PN2), c.ws(W_PN3)));
-  CK(drq_trunc_normal_sample(c.ws(W_PN3), s->noise_critic, s->std, s->clip, 1, nullptr, c.ws(W_HA_T) + F, FA, B, A, st));
-  CK(q_forward(c, P.target, c.ws(W_HA_T), c.ws(W_T1), c.ws(W_T2), c.ws(W_TQ)));
-  // critic(obs, action) (:188)
+  // target: a' ~ TruncN(actor(next)), y = r + d*min Q_target(next, a')   (:180-186);  critic(obs, action) (:188)
+  CK(drq_trunc_normal_sample(c.ws(W_P3) + (long)B * A, s->noise_critic, s->std, s->clip, 1, nullptr,
+                             c.ws(W_HA_T) + F, FA, B, A, st));
   CK(drq_copy_cols(s->action, A, c.ws(W_HA_C) + F, FA, B, A, st));
-  CK(q_forward(c, P.critic, c.ws(W_HA_C), c.ws(W_C1), c.ws(W_C2), c.ws(W_Q)));
+  {
+    const HeadOff* nets[2] = {&tg, &cr};
+    const float* ha[2] = {c.ws(W_HA_T), c.ws(W_HA_C)};
+    float* h1[2] = {c.ws(W_T1), c.ws(W_C1)};
+    float* h2[2] = {c.ws(W_T2), c.ws(W_C2)};
+    float* q[2] = {c.ws(W_TQ), c.ws(W_Q)};
+    CK(q_forward(c, 2, nets, ha, h1, h2, q));
+  }
   const float invB = 1.0f / (float)s->global_B;
   CK(drq_td_mse(c.ws(W_TQ), c.ws(W_TQ) + B, c.ws(W_Q), c.ws(W_Q) + B, s->reward, s->discount, c.ws(W_DQ),
                 c.ws(W_DQ) + B, s->sums, B, invB, st));
 
-  // ---- backward of the critic loss (:200)
-  const HeadOff& cr = P.critic;
-  const long wbs = cr.w[1][0] - cr.w[0][0];
-  const long BH = (long)B * H;
-  // layer 3: q = h2 W3^T + b3
-  CK(c.linear_wgrad(c.ws(W_DQ), 1, B, c.ws(W_C2), H, BH, c.g(cr.w[0][2]), wbs, c.g(cr.b[0][2]), wbs, B, 1, H, 2));
-  CK(c.linear_dgrad(c.ws(W_DQ), 1, B, c.p(cr.w[0][2]), H, wbs, c.ws(W_DC2), H, BH, B, H, 1, 2, c.ws(W_C2), H, BH));
-  // layer 2
-  CK(c.linear_wgrad(c.ws(W_DC2), H, BH, c.ws(W_C1), H, BH, c.g(cr.w[0][1]), wbs, c.g(cr.b[0][1]), wbs, B, H, H, 2));
-  CK(c.linear_dgrad(c.ws(W_DC2), H, BH, c.p(cr.w[0][1]), H, wbs, c.ws(W_DC1), H, BH, B, H, H, 2, c.ws(W_C1), H, BH));
-  // layer 1 (input = [h, action], shared by both heads)
-  CK(c.linear_wgrad(c.ws(W_DC1), H, BH, c.ws(W_HA_C), FA, 0, c.g(cr.w[0][0]), wbs, c.g(cr.b[0][0]), wbs, B, H, FA, 2));
-  CK(c.linear_dgrad(c.ws(W_DC1), H, BH, c.p(cr.w[0][0]), FA, wbs, c.ws(W_DHA), FA, (long)B * FA, B, FA, H, 2, nullptr,
-                    0, 0));
+  // ---- backward of the critic loss (:200), both heads per launch
+  {
+    float *c1[2] = {c.ws(W_C1), c.ws(W_C1) + BH}, *c2[2] = {c.ws(W_C2), c.ws(W_C2) + BH};
+    float *dc1[2] = {c.ws(W_DC1), c.ws(W_DC1) + BH}, *dc2[2] = {c.ws(W_DC2), c.ws(W_DC2) + BH};
+    float* dha[2] = {c.ws(W_DHA), c.ws(W_DHA) + (long)B * FA};
+    const float *dq[2] = {c.ws(W_DQ), c.ws(W_DQ) + B};
+    const float *c1c[2] = {c1[0], c1[1]}, *c2c[2] = {c2[0], c2[1]}, *dc1c[2] = {dc1[0], dc1[1]},
+                *dc2c[2] = {dc2[0], dc2[1]}, *hac[2] = {c.ws(W_HA_C), c.ws(W_HA_C)};
+    const float *w0[2] = {c.p(cr.w[0][0]), c.p(cr.w[1][0])}, *w1[2] = {c.p(cr.w[0][1]), c.p(cr.w[1][1])},
+                *w2[2] = {c.p(cr.w[0][2]), c.p(cr.w[1][2])};
+    float *gw0[2] = {c.g(cr.w[0][0]), c.g(cr.w[1][0])}, *gw1[2] = {c.g(cr.w[0][1]), c.g(cr.w[1][1])},
+          *gw2[2] = {c.g(cr.w[0][2]), c.g(cr.w[1][2])};
+    float *gb0[2] = {c.g(cr.b[0][0]), c.g(cr.b[1][0])}, *gb1[2] = {c.g(cr.b[0][1]), c.g(cr.b[1][1])},
+          *gb2[2] = {c.g(cr.b[0][2]), c.g(cr.b[1][2])};
+    // layer 3 (hidden -> 1): dgrad + wgrad + bias grad in one pass
+    CK(drq_qout_bwd(2, dq, c2c, w2, dc2, gw2, gb2, B, H, st));
+    // layer 2
+    CK(c.wgrad(2, dc2c, H, c1c, H, gw1, gb1, B, H, H));
+    CK(c.dgrad(2, dc2c, H, w1, H, dc1, H, B, H, H, c1c, H));
+    // layer 1 (input = [h, action], shared by both heads)
+    CK(c.wgrad(2, dc1c, H, hac, FA, gw0, gb0, B, H, FA));
+    CK(c.dgrad(2, dc1c, H, w0, FA, dha, FA, B, FA, H, nullptr, 0));
+  }
   // trunk: LayerNorm+tanh backward, then Linear(R -> F)
   CK(drq_ln_tanh_bwd(c.ws(W_DHA), FA, c.ws(W_DHA) + (long)B * FA, FA, c.ws(W_HA_C), FA, c.ws(W_XHAT_C),
                      c.ws(W_RSTD_C), c.p(cr.ln_g), c.ws(W_DZ_C), c.ws(W_DLN), c.g(cr.ln_g), c.g(cr.ln_b), B, F, st));
-  CK(c.linear_wgrad(c.ws(W_DZ_C), F, 0, feat_obs, R, 0, c.g(cr.trunk_w), 0, c.g(cr.trunk_b), 0, B, F, (int)R, 1));
-  // d feat = dz W_t, masked by relu(conv4) and scattered into the padded conv-gradient layout
-  CK(drq_gemm_f32(c.ws(W_DZ_C), F, 1, c.p(cr.trunk_w), R, 0, c.ws(W_DY4), 0, B, (int)R, F, 1, 0, 0, 0, nullptr, 0, 0,
-                  feat_obs, (int)R, 0, 35, 0, 1, c.gemm_ws(), c.gemm_ws_bytes(), st));
+  {
+    const float *dz[1] = {c.ws(W_DZ_C)}, *x[1] = {feat_obs}, *w[1] = {c.p(cr.trunk_w)}, *mk[1] = {feat_obs};
+    float *gw[1] = {c.g(cr.trunk_w)}, *gb[1] = {c.g(cr.trunk_b)}, *dy4[1] = {c.ws(W_DY4)};
+    CK(c.wgrad(1, dz, F, x, R, gw, gb, B, F, (int)R));
+    // d feat = dz W_t, masked by relu(conv4) and scattered into the padded conv-gradient layout
+    CK(drq_gemm_batched_f32(1, dz, F, 1, w, R, 0, dy4, 0, B, (int)R, F, nullptr, 0, mk, (int)R, nullptr, 35, 0, 1,
+                            c.gemm_ws(), c.gemm_ws_bytes(), st));
+  }
 
   // ---- encoder backward: conv4 .. conv1 (wgrad all, dgrad 4..2)
   const int dyid[4] = {W_DY1, W_DY2, W_DY3, W_DY4};
@@ -308,6 +354,8 @@ int phase_actor(const Ctx& c) {
   const int B = s->B, A = s->A, F = s->F, H = s->H, FA = F + A;
   hipStream_t st = c.st;
   float* feat_obs = c.ws(W_FEAT);
+  const HeadOff &cr = P.critic, &ac = P.actor;
+  const long BH = (long)B * H;
 
   // critic_opt.step(); encoder_opt.step() (:201-202) + Polyak (:259-260, fused: it reads the stepped critic)
   CK(drq_adam_flat(c.p(P.seg[2]), c.g(P.seg[2]), s->adam_m + P.seg[2], s->adam_v + P.seg[2], P.seg[3] - P.seg[2],
@@ -315,39 +363,63 @@ int phase_actor(const Ctx& c) {
   CK(drq_adam_flat(c.p(P.seg[0]), c.g(P.seg[0]), s->adam_m + P.seg[0], s->adam_v + P.seg[0], P.seg[1] - P.seg[0],
                    s->lr, s->step_enc, s->gscale, nullptr, 0.0, st));
 
-  // actor(obs.detach()) (:210-211)
-  CK(policy_forward(c, c.ws(W_H_AO), c.ws(W_PO1), c.ws(W_PO2), c.ws(W_PO3)));
-  CK(drq_trunc_normal_sample(c.ws(W_PO3), s->noise_actor, s->std, s->clip, 1, c.ws(W_MU_O), c.ws(W_HA_C2) + F, FA, B,
+  // a ~ TruncN(actor(obs.detach())) (:210-211): the policy MLP output for the obs rows was computed in phase 0
+  CK(drq_trunc_normal_sample(c.ws(W_P3), s->noise_actor, s->std, s->clip, 1, c.ws(W_MU_O), c.ws(W_HA_C2) + F, FA, B,
                              A, st));
   // updated critic on (obs, a) (:213)
-  const HeadOff& cr = P.critic;
-  CK(c.linear_fwd(feat_obs, R, 0, c.p(cr.trunk_w), 0, c.p(cr.trunk_b), 0, c.ws(W_Z_C2), F, 0, B, F, (int)R, 1, 0));
+  {
+    const float *x[1] = {feat_obs}, *w[1] = {c.p(cr.trunk_w)}, *b[1] = {c.p(cr.trunk_b)};
+    float* y[1] = {c.ws(W_Z_C2)};
+    CK(c.fwd(1, x, R, w, b, y, F, B, F, (int)R, 0));
+  }
   CK(drq_ln_tanh_fwd(c.ws(W_Z_C2), F, c.p(cr.ln_g), c.p(cr.ln_b), c.ws(W_HA_C2), FA, nullptr, nullptr, B, F, st));
-  CK(q_forward(c, cr, c.ws(W_HA_C2), c.ws(W_T1), c.ws(W_T2), c.ws(W_TQ)));
+  {
+    const HeadOff* nets[1] = {&cr};
+    const float* ha[1] = {c.ws(W_HA_C2)};
+    float *h1[1] = {c.ws(W_T1)}, *h2[1] = {c.ws(W_T2)}, *q[1] = {c.ws(W_TQ)};
+    CK(q_forward(c, 1, nets, ha, h1, h2, q));
+  }
   const float invB = 1.0f / (float)s->global_B;
   CK(drq_actor_loss(c.ws(W_TQ), c.ws(W_TQ) + B, c.ws(W_HA_C2) + F, FA, c.ws(W_MU_O), s->std, c.ws(W_DQ),
                     c.ws(W_DQ) + B, s->sums, B, A, invB, st));
 
   // backward through the critic to the action only (critic weight grads are never used: SURVEY A7(iii))
-  const long wbs = cr.w[1][0] - cr.w[0][0];
-  const long BH = (long)B * H;
-  CK(c.linear_dgrad(c.ws(W_DQ), 1, B, c.p(cr.w[0][2]), H, wbs, c.ws(W_DC2), H, BH, B, H, 1, 2, c.ws(W_T2), H, BH));
-  CK(c.linear_dgrad(c.ws(W_DC2), H, BH, c.p(cr.w[0][1]), H, wbs, c.ws(W_DC1), H, BH, B, H, H, 2, c.ws(W_T1), H, BH));
-  CK(c.linear_dgrad(c.ws(W_DC1), H, BH, c.p(cr.w[0][0]) + F, FA, wbs, c.ws(W_DA), A, (long)B * A, B, A, H, 2, nullptr,
-                    0, 0));
+  {
+    const float *dq[2] = {c.ws(W_DQ), c.ws(W_DQ) + B};
+    const float *t1[2] = {c.ws(W_T1), c.ws(W_T1) + BH}, *t2[2] = {c.ws(W_T2), c.ws(W_T2) + BH};
+    float *dc1[2] = {c.ws(W_DC1), c.ws(W_DC1) + BH}, *dc2[2] = {c.ws(W_DC2), c.ws(W_DC2) + BH};
+    const float *dc1c[2] = {dc1[0], dc1[1]}, *dc2c[2] = {dc2[0], dc2[1]};
+    const float *w0a[2] = {c.p(cr.w[0][0]) + F, c.p(cr.w[1][0]) + F}, *w1[2] = {c.p(cr.w[0][1]), c.p(cr.w[1][1])},
+                *w2[2] = {c.p(cr.w[0][2]), c.p(cr.w[1][2])};
+    float* da[2] = {c.ws(W_DA), c.ws(W_DA) + (long)B * A};
+    CK(drq_qout_bwd(2, dq, t2, w2, dc2, nullptr, nullptr, B, H, st));
+    CK(c.dgrad(2, dc2c, H, w1, H, dc1, H, B, H, H, t1, H));
+    CK(c.dgrad(2, dc1c, H, w0a, FA, da, A, B, A, H, nullptr, 0));     // action columns of layer 1 only
+  }
   CK(drq_actor_dmu(c.ws(W_DA), c.ws(W_DA) + (long)B * A, A, 0, c.ws(W_MU_O), c.ws(W_DPRE), B, A, st));
 
-  // policy MLP backward
-  const HeadOff& ac = P.actor;
-  CK(c.linear_wgrad(c.ws(W_DPRE), A, 0, c.ws(W_PO2), H, 0, c.g(ac.w[0][2]), 0, c.g(ac.b[0][2]), 0, B, A, H, 1));
-  CK(c.linear_dgrad(c.ws(W_DPRE), A, 0, c.p(ac.w[0][2]), H, 0, c.ws(W_DP2), H, 0, B, H, A, 1, c.ws(W_PO2), H, 0));
-  CK(c.linear_wgrad(c.ws(W_DP2), H, 0, c.ws(W_PO1), H, 0, c.g(ac.w[0][1]), 0, c.g(ac.b[0][1]), 0, B, H, H, 1));
-  CK(c.linear_dgrad(c.ws(W_DP2), H, 0, c.p(ac.w[0][1]), H, 0, c.ws(W_DP1), H, 0, B, H, H, 1, c.ws(W_PO1), H, 0));
-  CK(c.linear_wgrad(c.ws(W_DP1), H, 0, c.ws(W_H_AO), F, 0, c.g(ac.w[0][0]), 0, c.g(ac.b[0][0]), 0, B, H, F, 1));
-  CK(c.linear_dgrad(c.ws(W_DP1), H, 0, c.p(ac.w[0][0]), F, 0, c.ws(W_DH_A), F, 0, B, F, H, 1, nullptr, 0, 0));
-  CK(drq_ln_tanh_bwd(c.ws(W_DH_A), F, nullptr, 0, c.ws(W_H_AO), F, c.ws(W_XHAT_A), c.ws(W_RSTD_A), c.p(ac.ln_g),
+  // policy MLP backward (rows [0,B) of the stacked activations are the obs rows)
+  {
+    const float *dpre[1] = {c.ws(W_DPRE)}, *p1[1] = {c.ws(W_P1)}, *p2[1] = {c.ws(W_P2)}, *h[1] = {c.ws(W_HROWS)};
+    float *dp1[1] = {c.ws(W_DP1)}, *dp2[1] = {c.ws(W_DP2)}, *dh[1] = {c.ws(W_DH_A)};
+    const float *dp1c[1] = {dp1[0]}, *dp2c[1] = {dp2[0]};
+    const float *w0[1] = {c.p(ac.w[0][0])}, *w1[1] = {c.p(ac.w[0][1])}, *w2[1] = {c.p(ac.w[0][2])};
+    float *gw0[1] = {c.g(ac.w[0][0])}, *gw1[1] = {c.g(ac.w[0][1])}, *gw2[1] = {c.g(ac.w[0][2])};
+    float *gb0[1] = {c.g(ac.b[0][0])}, *gb1[1] = {c.g(ac.b[0][1])}, *gb2[1] = {c.g(ac.b[0][2])};
+    CK(c.wgrad(1, dpre, A, p2, H, gw2, gb2, B, A, H));
+    CK(c.dgrad(1, dpre, A, w2, H, dp2, H, B, H, A, p2, H));
+    CK(c.wgrad(1, dp2c, H, p1, H, gw1, gb1, B, H, H));
+    CK(c.dgrad(1, dp2c, H, w1, H, dp1, H, B, H, H, p1, H));
+    CK(c.wgrad(1, dp1c, H, h, F, gw0, gb0, B, H, F));
+    CK(c.dgrad(1, dp1c, H, w0, F, dh, F, B, F, H, nullptr, 0));
+  }
+  CK(drq_ln_tanh_bwd(c.ws(W_DH_A), F, nullptr, 0, c.ws(W_HROWS), F, c.ws(W_XHAT_A), c.ws(W_RSTD_A), c.p(ac.ln_g),
                      c.ws(W_DZ_A), c.ws(W_DLN), c.g(ac.ln_g), c.g(ac.ln_b), B, F, st));
-  CK(c.linear_wgrad(c.ws(W_DZ_A), F, 0, feat_obs, R, 0, c.g(ac.trunk_w), 0, c.g(ac.trunk_b), 0, B, F, (int)R, 1));
+  {
+    const float *dz[1] = {c.ws(W_DZ_A)}, *x[1] = {feat_obs};
+    float *gw[1] = {c.g(ac.trunk_w)}, *gb[1] = {c.g(ac.trunk_b)};
+    CK(c.wgrad(1, dz, F, x, R, gw, gb, B, F, (int)R));
+  }
   return 0;
 }
 
@@ -416,13 +488,16 @@ int drq_act_forward(const DrqStep* s, const uint8_t* obs, int n, float* mu_out) 
   CK(drq_u8_normalize(obs, c.ws(W_AUG), (long)n * s->C * 84 * 84, c.st));
   CK(encoder_forward(c, c.ws(W_AUG), n, c.ws(W_ACT1), c.ws(W_ACT2), c.ws(W_ACT3), c.ws(W_FEAT)));
   const HeadOff& a = P.actor;
-  // n <= 2B rows: z and the hidden activations fit the [2][B] sized buffers
-  CK(c.linear_fwd(c.ws(W_FEAT), R, 0, c.p(a.trunk_w), 0, c.p(a.trunk_b), 0, c.ws(W_Z_OBS), F, 0, n, F, (int)R, 1, 0));
-  CK(drq_ln_tanh_fwd(c.ws(W_Z_OBS), F, c.p(a.ln_g), c.p(a.ln_b), c.ws(W_Z_NEXT), F, nullptr, nullptr, n, F, c.st));
-  CK(c.linear_fwd(c.ws(W_Z_NEXT), F, 0, c.p(a.w[0][0]), 0, c.p(a.b[0][0]), 0, c.ws(W_T1), H, 0, n, H, F, 1, 1));
-  CK(c.linear_fwd(c.ws(W_T1), H, 0, c.p(a.w[0][1]), 0, c.p(a.b[0][1]), 0, c.ws(W_T2), H, 0, n, H, H, 1, 1));
-  CK(c.linear_fwd(c.ws(W_T2), H, 0, c.p(a.w[0][2]), 0, c.p(a.b[0][2]), 0, c.ws(W_DA), A, 0, n, A, H, 1, 0));
-  return drq_tanh(c.ws(W_DA), mu_out, (long)n * A, c.st);
+  // n <= 2B rows: every buffer used below holds 2B rows
+  {
+    const float *x[1] = {c.ws(W_FEAT)}, *w[1] = {c.p(a.trunk_w)}, *b[1] = {c.p(a.trunk_b)};
+    float* y[1] = {c.ws(W_Z4)};
+    CK(c.fwd(1, x, R, w, b, y, F, n, F, (int)R, 0));
+  }
+  CK(drq_ln_tanh_fwd(c.ws(W_Z4), F, c.p(a.ln_g), c.p(a.ln_b), c.ws(W_HROWS), F, nullptr, nullptr, n, F, c.st));
+  CK(policy_forward(c, c.ws(W_HROWS), n, c.ws(W_P1), c.ws(W_P2), c.ws(W_P3)));
+  (void)H;
+  return drq_tanh(c.ws(W_P3), mu_out, (long)n * A, c.st);
 }
 
 }  // extern "C"

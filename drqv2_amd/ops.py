@@ -185,3 +185,48 @@ def tanh(x):
     y = torch.empty_like(x)
     check(lib.drq_tanh(ptr(x), ptr(y), x.numel(), _stream()), "drq_tanh")
     return y
+
+
+def _ptr_array(ts):
+    """host array of device pointers (None entries allowed) for the batched entry points."""
+    import ctypes
+    return (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+
+
+def gemm_batched(As, a_kc, Bs, b_kc, M, N, K, lda, ldb, biases=None, relu=False, auxs=None, rowsum=False, tile=0,
+                 splitk=0):
+    """n independent problems of one shape in a single launch.  Returns (list of C, list of rowsum or None)."""
+    lib = _lib.load()
+    n = len(As)
+    dev = As[0].device
+    Cs = [torch.empty((M, N), device=dev, dtype=torch.float32) for _ in range(n)]
+    rs = [torch.empty((M,), device=dev, dtype=torch.float32) for _ in range(n)] if rowsum else None
+    ws = torch.empty((16 * 1024 * 1024,), device=dev, dtype=torch.float32)
+    check(lib.drq_gemm_batched_f32(n, _ptr_array(As), lda, int(a_kc), _ptr_array(Bs), ldb, int(b_kc), _ptr_array(Cs),
+                                   N, M, N, K, _ptr_array(biases) if biases else None, int(relu),
+                                   _ptr_array(auxs) if auxs else None, (auxs[0].shape[-1] if auxs else 0),
+                                   _ptr_array(rs) if rs else None, 0, tile, splitk, ptr(ws), ws.numel() * 4,
+                                   _stream()), "drq_gemm_batched_f32")
+    return Cs, rs
+
+
+def qout_fwd(hs, ws_, bs):
+    lib = _lib.load()
+    B, H = hs[0].shape
+    qs = [torch.empty((B,), device=hs[0].device, dtype=torch.float32) for _ in hs]
+    check(lib.drq_qout_fwd(len(hs), _ptr_array(hs), _ptr_array(ws_), _ptr_array(bs), _ptr_array(qs), B, H, _stream()),
+          "drq_qout_fwd")
+    return qs
+
+
+def qout_bwd(dqs, hs, ws_, want_wgrad=True):
+    lib = _lib.load()
+    B, H = hs[0].shape
+    dev = hs[0].device
+    dhs = [torch.empty((B, H), device=dev, dtype=torch.float32) for _ in hs]
+    dws = [torch.empty((H,), device=dev, dtype=torch.float32) for _ in hs] if want_wgrad else None
+    dbs = [torch.empty((1,), device=dev, dtype=torch.float32) for _ in hs] if want_wgrad else None
+    check(lib.drq_qout_bwd(len(hs), _ptr_array(dqs), _ptr_array(hs), _ptr_array(ws_), _ptr_array(dhs),
+                           _ptr_array(dws) if dws else None, _ptr_array(dbs) if dbs else None, B, H, _stream()),
+          "drq_qout_bwd")
+    return dhs, dws, dbs

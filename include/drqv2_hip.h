@@ -59,12 +59,30 @@ int drq_gemm_f32(const float* A, long lda, int a_kc, const float* B, long ldb, i
                  int relu, const float* aux, int ldaux, long aux_bs, int scatter_hw, int tile, int splitk,
                  float* ws, size_t ws_bytes, drq_stream_t stream);
 
+/* same GEMM for nbatch (<= 8) problems of one shape with independent pointers (host arrays of device
+ * pointers; bias / aux / rowsum arrays may be NULL).  rowsum[b] != NULL (needs a_kc == 0): also writes
+ * rowsum[b][m] = sum_k A_b(m,k), i.e. the bias gradient of a wgrad GEMM, without a second pass. */
+int drq_gemm_batched_f32(int nbatch, const float* const* A, long lda, int a_kc, const float* const* B, long ldb,
+                         int b_kc, float* const* C, long ldc, int M, int N, int K, const float* const* bias, int relu,
+                         const float* const* aux, int ldaux, float* const* rowsum, int scatter_hw, int tile,
+                         int splitk, float* ws, size_t ws_bytes, drq_stream_t stream);
+
+/* ---- output layer of the Q heads, nn.Linear(hidden, 1) (drqv2.py:106,111), nz (<= 8) problems per launch:
+ * q = h w^T + b;  backward: dh = (dq w) * (h > 0), and if dw/db are given dw = dq^T h, db = sum dq. */
+int drq_qout_fwd(int nz, const float* const* h, const float* const* w, const float* const* b, float* const* q, int B,
+                 int H, drq_stream_t stream);
+int drq_qout_bwd(int nz, const float* const* dq, const float* const* h, const float* const* w, float* const* dh,
+                 float* const* dw, float* const* db, int B, int H, drq_stream_t stream);
+
 /* ---- nn.LayerNorm(F)+nn.Tanh (drqv2.py:74-75,100-101), eps 1e-5, F <= 256 */
 int drq_ln_tanh_fwd(const float* z, int ldz, const float* gamma, const float* beta, float* out, int ldo,
                     float* xhat, float* rstd, int rows, int F, drq_stream_t stream);
 int drq_ln_tanh_fwd2(const float* z0, const float* z1, int ldz, const float* gamma0, const float* beta0,
                      const float* gamma1, const float* beta1, float* out0, int ldo0, float* out1, int ldo1,
                      float* xhat0, float* rstd0, float* xhat1, float* rstd1, int rows, int F, drq_stream_t stream);
+int drq_ln_tanh_fwd_multi(int n, const float* const* z, int ldz, const float* const* gamma, const float* const* beta,
+                          float* const* out, const int* ldo, float* const* xhat, float* const* rstd, int rows, int F,
+                          drq_stream_t stream);
 int drq_ln_tanh_bwd(const float* dh0, int ld0, const float* dh1, int ld1, const float* h, int ldh,
                     const float* xhat, const float* rstd, const float* gamma, float* dz, float* dln,
                     float* dgamma, float* dbeta, int rows, int F, drq_stream_t stream);

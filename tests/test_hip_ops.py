@@ -202,3 +202,47 @@ def test_unsupported_shapes_are_refused(ops):
         ops.conv3x3_fwd(x, w, torch.zeros(32, device="cuda"), 1)
     with pytest.raises(_lib.DrqError):
         ops.conv3x3_fwd(x.cpu(), w, torch.zeros(32), 1)
+
+
+@pytest.mark.parametrize("Brows,N,K,n", [(256, 1024, 1024, 2), (9, 50, 39200, 1), (31, 1024, 56, 2), (12, 6, 1024, 1),
+                                         (40, 70, 33, 3)])
+def test_gemm_batched_wgrad_with_fused_bias_grad(ops, Brows, N, K, n):
+    """dW_i = dy_i^T x_i and db_i = column sums of dy_i from ONE launch, independent pointers per problem"""
+    dys = [rnd(Brows, N, seed=10 + i) for i in range(n)]
+    xs = [rnd(Brows, K, seed=20 + i) for i in range(n)]
+    Cs, rs = ops.gemm_batched([t.cuda() for t in dys], False, [t.cuda() for t in xs], False, N, K, Brows, N, K,
+                              rowsum=True)
+    for dy, x, c, r in zip(dys, xs, Cs, rs):
+        assert nerr(c, dy.double().t() @ x.double()) <= 3e-6
+        assert nerr(r, dy.double().sum(0)) <= 3e-6
+
+
+def test_gemm_batched_forward_four_problems(ops):
+    M, N, K = 64, 50, 2048
+    xs = [rnd(M, K, seed=i) for i in range(2)]
+    wts = [rnd(N, K, seed=5 + i, scale=K ** -0.5) for i in range(4)]
+    bs = [rnd(N, seed=9 + i) for i in range(4)]
+    A = [xs[0].cuda(), xs[0].cuda(), xs[1].cuda(), xs[1].cuda()]
+    Cs, _ = ops.gemm_batched(A, True, [w.cuda() for w in wts], True, M, N, K, K, K, biases=[b.cuda() for b in bs],
+                             relu=True)
+    for i, c in enumerate(Cs):
+        ref = torch.relu(xs[i // 2].double() @ wts[i].double().t() + bs[i].double())
+        assert nerr(c, ref) <= 3e-6
+
+
+@pytest.mark.parametrize("B,H,n", [(256, 1024, 4), (7, 64, 2), (33, 100, 1)])
+def test_qout_fwd_bwd(ops, B, H, n):
+    hs = [rnd(B, H, seed=i).clamp_min(0) for i in range(n)]
+    ws_ = [rnd(H, seed=10 + i, scale=H ** -0.5) for i in range(n)]
+    bs = [rnd(1, seed=20 + i) for i in range(n)]
+    dqs = [rnd(B, seed=30 + i) for i in range(n)]
+    qs = ops.qout_fwd([t.cuda() for t in hs], [t.cuda() for t in ws_], [t.cuda() for t in bs])
+    for h, w, b, q in zip(hs, ws_, bs, qs):
+        assert nerr(q, h.double() @ w.double() + b.double()) <= 2e-6
+    dhs, dws, dbs = ops.qout_bwd([t.cuda() for t in dqs], [t.cuda() for t in hs], [t.cuda() for t in ws_])
+    for dq, h, w, dh, dw, db in zip(dqs, hs, ws_, dhs, dws, dbs):
+        assert nerr(dh, torch.outer(dq.double(), w.double()) * (h > 0).double()) <= 2e-6
+        assert nerr(dw, dq.double() @ h.double()) <= 3e-6
+        assert nerr(db, dq.double().sum().view(1)) <= 3e-6
+    dhs2, dws2, _ = ops.qout_bwd([t.cuda() for t in dqs], [t.cuda() for t in hs], [t.cuda() for t in ws_], False)
+    assert dws2 is None and all(torch.equal(a, b) for a, b in zip(dhs, dhs2))
