@@ -207,7 +207,7 @@ class DrQV2Agent:
                           self.critic_target_tau, B_global=n_global)
 
         if self.use_tb:
-            s = sums.tolist()            # the single device->host sync of the update
+            s = eng.read_sums()          # the single device->host wait of the update
             inv = 1.0 / n_global
             metrics["batch_reward"] = s[0] * inv
             metrics["critic_target_q"] = s[1] * inv

@@ -27,6 +27,7 @@ class DrqStep(C.Structure):
         ("step_critic", C.c_long), ("step_enc", C.c_long), ("step_actor", C.c_long),
         ("gscale", C.c_float),
         ("stream", stream_t),
+        ("sums_host", c_float_p),
     ]
 
 
@@ -90,7 +91,7 @@ def load():
         fn = getattr(lib, name)       # AttributeError = ABI mismatch, also loud
         fn.restype = res
         fn.argtypes = args
-    if lib.drq_abi_version() != 1:
+    if lib.drq_abi_version() != 2:
         raise DrqError("libdrqv2_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

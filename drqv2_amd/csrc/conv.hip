@@ -38,48 +38,75 @@ struct ConvArgs {
   int nb;
   int relu;
   int wmode;           // 0 forward gather, 1 dgrad gather (transposed + flipped)
+  unsigned long long* stamps;   // development only (ABL & 4): per-wave s_memtime stamps, 32 per wave
 };
+
+unsigned long long* g_conv_stamps = nullptr;   // set by drq_dev_conv_stamps (undeclared development hook)
 
 // BLK = workgroups per CU the kernel is tuned for (8 waves each): 2 -> 4 waves/SIMD (<=128 VGPR)
 // ABL (development only): 1 = skip the input loads, 2 = skip the LDS weight reads, 3 = both (timing ablations)
-template <int CIN, int HIN, int STRIDE, int BLK, int TPW, int ABL = 0>
+// MASK: the epilogue multiplies by (mask > 0) (dgrad through the ReLU of the layer below)
+template <int CIN, int HIN, int STRIDE, int BLK, int TPW, int ABL = 0, bool MASK = false>
 __global__ __launch_bounds__(512, 2 * BLK) void conv3x3_kernel(ConvArgs a) {
   constexpr int CP = (CIN + 1) / 2;
   constexpr int NS = CP * 9;                 // MFMA steps per tile
   constexpr int HOUT = (HIN - 3) / STRIDE + 1;
   constexpr int P = HOUT * HOUT;
-  __shared__ float wl[NS * 64];              // A operand, [step][lane]
+  constexpr int WP = 73;                     // LDS pitch of one MFMA step (64 lanes + bank-spreading pad)
+  __shared__ float wl[NS * WP];              // A operand, [step][lane]
   __shared__ float bl[32];                   // bias
 
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
+  unsigned long long* stamp = nullptr;
+  int nstamp = 0;
+  auto mark = [&]() {
+    if constexpr (ABL & 4) {
+      if (stamp && nstamp < 30 && lane == 0) stamp[nstamp] = __builtin_amdgcn_s_memtime();
+      ++nstamp;
+    }
+  };
+  if constexpr (ABL & 4) {
+    if (a.stamps) {
+      stamp = a.stamps + ((size_t)blockIdx.x * 8 + wid) * 32;
+      if (lane == 0) {
+        stamp[30] = __builtin_amdgcn_s_memrealtime();
+        stamp[31] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID, all 32 bits
+      }
+    }
+  }
+  mark();
   const int col = lane & 31;   // MFMA: A row (cout) for the weights, B column (pixel) for the input
   const int half = lane >> 5;  // k parity -> channel parity
 
-  // weight gather -> LDS: fixed trip count, fully unrolled, so all of a thread's loads are in flight at once
-  // (a rolled loop serialises ~18 L2 round trips at the start of every workgroup)
+  // weights -> LDS.  Global reads are contiguous (thread i takes canonical elements i, i+512, ...: a lane-ordered
+  // GATHER from global memory touches one 128-byte line per lane and cost several us per workgroup); the
+  // scatter into MFMA-lane order happens on the LDS side, where the step pitch WP = 73 (= 9 mod 64) spreads the
+  // (tap, channel) neighbours of one wave over distinct banks in both gather modes.
   {
-    constexpr int NIT = (NS * 64 + 511) / 512;
+    constexpr int NW = 32 * CIN * 9;
+    constexpr int NIT = (NW + 511) / 512;
     float wv[NIT];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int idx = min(it * 512 + (int)threadIdx.x, NS * 64 - 1);
-      const int step = idx >> 6, l = idx & 63;
-      const int c = step / 9, t = step - 9 * c;
-      const int kc = min(2 * c + (l >> 5), CIN - 1), row = l & 31;
-      wv[it] = a.w[(a.wmode == 0) ? (row * CIN + kc) * 9 + t : (kc * 32 + row) * 9 + (8 - t)];
+    for (int it = 0; it < NIT; ++it) wv[it] = a.w[min(it * 512 + (int)threadIdx.x, NW - 1)];
+    if constexpr (CIN & 1) {   // the missing odd channel of the last pair multiplies real inputs: must be 0
+      for (int i = threadIdx.x; i < 9 * 32; i += 512) wl[((CP - 1) * 9 + (i >> 5)) * WP + 32 + (i & 31)] = 0.f;
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int idx = it * 512 + (int)threadIdx.x;
-      if (idx < NS * 64) {
-        const int step = idx >> 6, l = idx & 63;
-        wl[idx] = (2 * (step / 9) + (l >> 5) < CIN) ? wv[it] : 0.f;
+      if (idx < NW) {
+        const int t = idx % 9, q = idx / 9;
+        int kc, row, tt;
+        if (a.wmode == 0) { row = q / CIN; kc = q - row * CIN; tt = t; }      // w[row=cout][kc=cin][t]
+        else              { kc = q >> 5;   row = q & 31;       tt = 8 - t; }  // w[kc=cout][row=cin][8-t]
+        wl[((kc >> 1) * 9 + tt) * WP + (kc & 1) * 32 + row] = wv[it];
       }
     }
   }
   if (threadIdx.x < 32) bl[threadIdx.x] = a.bias ? a.bias[threadIdx.x] : 0.f;
   __syncthreads();
+  mark();
 
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
@@ -131,55 +158,72 @@ __global__ __launch_bounds__(512, 2 * BLK) void conv3x3_kernel(ConvArgs a) {
   // TPW pixel tiles per wave iteration: TPW independent accumulator chains share one A (weight) read,
   // so a wave always has an MFMA that does not depend on the one in flight.
   auto mfma_group = [&](f32x16 (&acc)[TPW], const float (&xv)[TPW][9], int c) {
-    const float* wp = wlane + c * (9 * 64);
+    const float* wp = wlane + c * (9 * WP);
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const float wv = (ABL & 2) ? __uint_as_float((unsigned)(c * 9 + t) + lane) : wp[t * 64];
+      const float wv = (ABL & 2) ? __uint_as_float((unsigned)(c * 9 + t) + lane) : wp[t * WP];
 #pragma unroll
       for (int j = 0; j < TPW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv, xv[j][t], acc[j], 0, 0, 0);
     }
   };
-  auto store_tile = [&](int tile, const f32x16& acc) {
-    const int p = tile * 32 + col;
-    if (tile >= t_end || p >= total) return;
+  // ---- epilogue pieces -----------------------------------------------------------------------------------------
+  // The waves of a SIMD run in lockstep (same work, round-robin MFMA issue): whatever one wave waits for between
+  // its last MFMA of a tile and its first of the next, the MFMA pipe waits for too.  vmcnt retires in order and
+  // the compiler can only count exactly in straight-line code, so
+  //   * the channel-pair loop of a tile is fully unrolled (every s_waitcnt carries an exact count),
+  //   * a finished tile is moved to 16 "out" registers (ReLU / mask applied) and its stores are issued two
+  //     stages into the NEXT tile, unconditionally (invalid lanes get an out-of-range offset: the buffer
+  //     descriptor drops them) -- a branch would merge two counter states and force a conservative wait,
+  //   * the mask loads and the address arithmetic (integer divisions) are issued in mid-tile stages.
+  constexpr int kDrop = (int)0x80000000u;   // beyond any num_records (< 2^31): the store is discarded
+  auto tile_out = [&](int tile, int& yoff, int& moff) {
+    const int p0 = tile * 32 + col;
+    const bool ok = tile < t_end && p0 < total;
+    const int p = p0 < total ? p0 : total - 1;
     const int b = p / P;
     const int rem = p - b * P;
     const int oy = rem / HOUT;
     const int ox = rem - oy * HOUT;
     // register r holds cout = (r&3) + 8*(r>>2) + 4*half: the 4*half part rides in the lane offset
-    const int yoff = ((int)a.y_off + b * (int)a.y_bs + oy * (int)a.y_rs + ox) * 4 + half * 4 * ycs4;
-    const int moff = ((b * 32 + 4 * half) * P + rem) * 4;
-    float mv[16];
+    yoff = ok ? ((int)a.y_off + b * (int)a.y_bs + oy * (int)a.y_rs + ox) * 4 + half * 4 * ycs4 : kDrop;
+    moff = ((b * 32 + 4 * half) * P + rem) * 4;
+  };
+  auto load_mask = [&](float (&mv)[16], int moff) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r)   // zero-sized descriptor (no mask): every load returns 0 and is ignored
+    for (int r = 0; r < 16; ++r)
       mv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(mrsrc, moff, ((r & 3) + 8 * (r >> 2)) * P * 4, 0));
-    const bool use_mask = a.mask != nullptr;
+  };
+  auto store_out = [&](const float (&o)[16], int yoff) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float v = acc[r];
-      if (a.relu) v = v > 0.f ? v : 0.f;
-      if (use_mask) v = mv[r] > 0.f ? v : 0.f;
-      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrsrc, yoff, ((r & 3) + 8 * (r >> 2)) * ycs4, 0);
-    }
+    for (int r = 0; r < 16; ++r)
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[r]), yrsrc, yoff, ((r & 3) + 8 * (r >> 2)) * ycs4, 0);
   };
 
-  // software pipeline over channel pairs: the taps of the next pair (or of the next tiles' first pair)
-  // are in flight while the MFMAs of the current pair issue; the other waves of the SIMD fill the rest.
-  float xa[TPW][9], xb[TPW][9];
-  int voff[TPW], nvoff[TPW];
+  // software pipeline over channel pairs ("stages"): the taps of the next stage (or of the next tile's first
+  // stage) are in flight while the MFMAs of the current one issue; the other waves of the SIMD fill the rest.
+  float X[2][TPW][9];
+  float out[TPW][16], mv[TPW][16];
+  int voff[TPW], nvoff[TPW], yoff[TPW], moff[TPW], out_yoff[TPW];
   int tile = t_beg + wid * TPW;
   auto clampt = [&](int t) { return t < t_end ? t : t_end - 1; };   // ragged end: harmless re-load
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    out_yoff[j] = kDrop;
+    nvoff[j] = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[j][r] = 0.f;
+  }
   if (tile < t_end) {
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
       voff[j] = tile_voff(clampt(tile + j));
-      load_group(xa[j], voff[j], 0);
+      load_group(X[0][j], voff[j], 0);
     }
   }
+  constexpr int kStoreStage = CP > 4 ? 2 : 0;              // previous tile's stores
+  constexpr int kPrepStage = CP > 4 ? CP - 4 : 0;          // next-tile / output addresses (needed at stage CP-1)
+  constexpr int kMaskStage = CP > 4 ? CP - 3 : 0;
   for (; tile < t_end; tile += 8 * TPW) {
-#pragma unroll
-    for (int j = 0; j < TPW; ++j) nvoff[j] = tile_voff(clampt(tile + 8 * TPW + j));
-
     // accumulator row (cout) of register r: (r&3) + 8*(r>>2) + 4*half; C-in = bias
     f32x16 acc[TPW];
 #pragma unroll
@@ -188,44 +232,59 @@ __global__ __launch_bounds__(512, 2 * BLK) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
       for (int j = 0; j < TPW; ++j) acc[j][r] = bv;
     }
-
-    if constexpr (CP % 2 == 0) {
-#pragma unroll 1
-      for (int c = 0; c < CP; c += 2) {
 #pragma unroll
-        for (int j = 0; j < TPW; ++j) load_group(xb[j], voff[j], c + 1);
-        mfma_group(acc, xa, c);
+    for (int c = 0; c < CP; ++c) {
+      if (c == kPrepStage) {
 #pragma unroll
         for (int j = 0; j < TPW; ++j) {
-          if (c + 2 < CP) load_group(xa[j], voff[j], c + 2);
-          else load_group(xa[j], nvoff[j], 0);
+          nvoff[j] = tile_voff(clampt(tile + 8 * TPW + j));
+          tile_out(tile + j, yoff[j], moff[j]);
         }
-        mfma_group(acc, xb, c + 1);
-      }
-    } else {
-#pragma unroll 1
-      for (int c = 0; c + 1 < CP; c += 2) {
-#pragma unroll
-        for (int j = 0; j < TPW; ++j) load_group(xb[j], voff[j], c + 1);
-        mfma_group(acc, xa, c);
-#pragma unroll
-        for (int j = 0; j < TPW; ++j) load_group(xa[j], voff[j], c + 2);
-        mfma_group(acc, xb, c + 1);
       }
 #pragma unroll
-      for (int j = 0; j < TPW; ++j) load_group(xb[j], nvoff[j], 0);
-      mfma_group(acc, xa, CP - 1);
+      for (int j = 0; j < TPW; ++j) {
+        if (c + 1 < CP) load_group(X[(c + 1) & 1][j], voff[j], c + 1);
+        else load_group(X[(c + 1) & 1][j], nvoff[j], 0);
+      }
+      if (c == kStoreStage) {
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) store_out(out[j], out_yoff[j]);
+      }
+      if constexpr (MASK) {
+        if (c == kMaskStage) {
+#pragma unroll
+          for (int j = 0; j < TPW; ++j) load_mask(mv[j], moff[j]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);   // memory instructions stay ahead of this stage's MFMAs
+      mfma_group(acc, X[c & 1], c);
+    }
+    if constexpr (CP & 1) {                // odd stage count: the next tile's first taps landed in X[1]
 #pragma unroll
       for (int j = 0; j < TPW; ++j)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) xa[j][t] = xb[j][t];
+        for (int t = 0; t < 9; ++t) X[0][j][t] = X[1][j][t];
     }
-
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
-      store_tile(tile + j, acc[j]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[j][r];
+        if (a.relu) v = v > 0.f ? v : 0.f;
+        if constexpr (MASK) v = mv[j][r] > 0.f ? v : 0.f;
+        out[j][r] = v;
+      }
+      out_yoff[j] = yoff[j];
       voff[j] = nvoff[j];
     }
+    if constexpr (ABL & 8) mark();
+  }
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) store_out(out[j], out_yoff[j]);   // the last tile of this wave
+  if constexpr (ABL & 4) {
+    __builtin_amdgcn_s_waitcnt(0);
+    mark();
+    if (stamp && lane == 0) stamp[29] = __builtin_amdgcn_s_memrealtime();
   }
 }
 
@@ -778,7 +837,7 @@ __global__ __launch_bounds__(1024) void conv3x3_wgrad_reduce_kernel(const float*
   }
 }
 
-template <int CIN, int HIN, int STRIDE, int BLK, int TPW, int ABL = 0>
+template <int CIN, int HIN, int STRIDE, int BLK, int TPW, int ABL = 0, bool MASK = false>
 int launch_conv_v(const ConvArgs& a, hipStream_t st) {
   constexpr int HOUT = (HIN - 3) / STRIDE + 1;
   const long ntiles = ((long)a.nb * HOUT * HOUT + 31) / 32;
@@ -786,12 +845,21 @@ int launch_conv_v(const ConvArgs& a, hipStream_t st) {
   const long cap = (long)BLK * drq_num_cus();
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((conv3x3_kernel<CIN, HIN, STRIDE, BLK, TPW, ABL>), dim3((unsigned)blocks), dim3(512), 0, st, a);
+  // Pin the residency to exactly BLK workgroups per CU: registers and the static LDS alone would admit BLK+1, and
+  // the dispatcher then packs BLK+1 on some CUs and leaves others short (a one-wave grid of equal-length
+  // workgroups then runs at the pace of the over-filled CUs: measured -12 % on an MFMA-only probe).  Unused
+  // dynamic LDS raises the group segment just past 160 KB / (BLK+1).
+  constexpr int NS = ((CIN + 1) / 2) * 9;
+  constexpr int static_lds = NS * 73 * 4 + 32 * 4;
+  constexpr int want = 160 * 1024 / (BLK + 1) + 1024;
+  const int pad = want > static_lds ? ((want - static_lds + 255) & ~255) : 0;
+  hipLaunchKernelGGL((conv3x3_kernel<CIN, HIN, STRIDE, BLK, TPW, ABL, MASK>), dim3((unsigned)blocks), dim3(512), pad, st,
+                     a);
   DRQ_LAUNCH_CHECK();
   return DRQ_OK;
 }
 
-// DRQ_CONV_VARIANT (development knob, read once): workgroups per CU x accumulator chains per wave
+// DRQ_CONV_VARIANT (development knob, read once): timing ablations of the forward kernel
 inline int conv_variant() {
   static int v = -1;
   if (v < 0) {
@@ -803,16 +871,24 @@ inline int conv_variant() {
 
 template <int CIN, int HIN, int STRIDE>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
+  if (a.mask) {
+    if constexpr (CIN == 32) return launch_conv_v<CIN, HIN, STRIDE, 2, 1, 0, true>(a, st);
+    else return DRQ_EARG;
+  }
   switch (conv_variant()) {
-    case 1: return launch_conv_v<CIN, HIN, STRIDE, 2, 2>(a, st);
+    case 1: return launch_conv_v<CIN, HIN, STRIDE, 2, 2>(a, st);        // 2 tiles per wave share each weight read
     case 2: return launch_conv_v<CIN, HIN, STRIDE, 1, 2>(a, st);
-    case 3: return launch_conv_v<CIN, HIN, STRIDE, 3, 1>(a, st);
-    case 4: return launch_conv_v<CIN, HIN, STRIDE, 1, 4>(a, st);
-    case 5: return launch_conv_v<CIN, HIN, STRIDE, 4, 1>(a, st);
-    case 6: return launch_conv_v<CIN, HIN, STRIDE, 2, 1, 1>(a, st);
-    case 7: return launch_conv_v<CIN, HIN, STRIDE, 2, 1, 2>(a, st);
-    case 8: return launch_conv_v<CIN, HIN, STRIDE, 2, 1, 3>(a, st);
-    case 9: return launch_conv_v<CIN, HIN, STRIDE, 1, 4, 3>(a, st);
+    case 4: return launch_conv_v<CIN, HIN, STRIDE, 1, 4>(a, st);        // 1 workgroup/CU, 4 accumulator chains/wave
+    case 6: return launch_conv_v<CIN, HIN, STRIDE, 2, 1, 1>(a, st);     // no input loads
+    case 7: return launch_conv_v<CIN, HIN, STRIDE, 2, 1, 2>(a, st);     // no LDS weight reads
+    case 8: return launch_conv_v<CIN, HIN, STRIDE, 2, 1, 3>(a, st);     // neither: MFMA + epilogue only
+    case 10: case 11: case 12: {                                        // + per-wave time stamps
+      ConvArgs b = a;
+      b.stamps = g_conv_stamps;
+      if (conv_variant() == 10) return launch_conv_v<CIN, HIN, STRIDE, 2, 1, 4>(b, st);        // start/end only
+      if (conv_variant() == 11) return launch_conv_v<CIN, HIN, STRIDE, 2, 1, 12>(b, st);       // + every tile
+      return launch_conv_v<CIN, HIN, STRIDE, 2, 1, 7>(b, st);                                  // MFMA only, start/end
+    }
     default: return launch_conv_v<CIN, HIN, STRIDE, 2, 1>(a, st);
   }
 }
@@ -894,6 +970,9 @@ int launch_wgrad(const WgradArgs& a0, float* dw, float* db, float* ws, size_t ws
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
+// development hook (not part of the ABI): device buffer of 32 u64 per wave for DRQ_CONV_VARIANT=10
+void drq_dev_conv_stamps(void* p) { g_conv_stamps = (unsigned long long*)p; }
+
 // y = relu?(conv3x3(x, w) + bias); x [nb][cin][hin][hin], y written with the given strides.
 int drq_conv3x3_fwd(const float* x, const float* w, const float* bias, float* y, int nb, int cin, int hin,
                     int stride, int relu, long y_bs, long y_cs, long y_rs, long y_off, hipStream_t st) {
@@ -902,7 +981,7 @@ int drq_conv3x3_fwd(const float* x, const float* w, const float* bias, float* y,
   if (xb >= (1ull << 31)) return DRQ_EARG;
   const size_t yb = (size_t)nb * y_bs * 4;
   if (yb >= (1ull << 31) || y_off < 0 || y_bs <= 0) return DRQ_EARG;
-  ConvArgs a{x, w, bias, nullptr, y, y_bs, y_cs, y_rs, y_off, (unsigned)xb, (unsigned)yb, 0u, nb, relu, 0};
+  ConvArgs a{x, w, bias, nullptr, y, y_bs, y_cs, y_rs, y_off, (unsigned)xb, (unsigned)yb, 0u, nb, relu, 0, nullptr};
   if (cin == 9 && hin == 84 && stride == 2) return launch_conv<9, 84, 2>(a, st);
   if (cin == 32 && stride == 1) {
     if (hin == 41) return launch_conv<32, 41, 1>(a, st);
@@ -924,7 +1003,7 @@ int drq_conv3x3_dgrad(const float* dy_pad, const float* w, const float* mask, fl
   const size_t mb = (size_t)nb * 32 * (hout + 2) * (hout + 2) * 4;
   if (yb >= (1ull << 31) || dx_off < 0 || dx_bs <= 0) return DRQ_EARG;
   ConvArgs a{dy_pad, w, nullptr, mask, dx, dx_bs, dx_cs, dx_rs, dx_off, (unsigned)xb, (unsigned)yb, (unsigned)mb,
-             nb, 0, 1};
+             nb, 0, 1, nullptr};
   if (hp == 39) return launch_conv<32, 39, 1>(a, st);
   if (hp == 41) return launch_conv<32, 41, 1>(a, st);
   if (hp == 43) return launch_conv<32, 43, 1>(a, st);

@@ -348,6 +348,14 @@ int phase_critic(const Ctx& c) {
 }
 
 // ---- phase 1 ---------------------------------------------------------------------------------
+// metrics mirror: sums -> pinned host memory, then the sequence word (system-scope release)
+__global__ void publish_sums_kernel(const float* sums, float* host, unsigned seq) {
+  if (threadIdx.x < 8) host[threadIdx.x] = sums[threadIdx.x];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store((unsigned*)(host + 8), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 int phase_actor(const Ctx& c) {
   const DrqStep* s = c.s;
   const ParamLayout& P = c.P;
@@ -382,6 +390,11 @@ int phase_actor(const Ctx& c) {
   const float invB = 1.0f / (float)s->global_B;
   CK(drq_actor_loss(c.ws(W_TQ), c.ws(W_TQ) + B, c.ws(W_HA_C2) + F, FA, c.ws(W_MU_O), s->std, c.ws(W_DQ),
                     c.ws(W_DQ) + B, s->sums, B, A, invB, st));
+  if (s->sums_host) {
+    hipLaunchKernelGGL(publish_sums_kernel, dim3(1), dim3(64), 0, st, (const float*)s->sums, s->sums_host,
+                       (unsigned)s->step_actor);
+    DRQ_LAUNCH_CHECK();
+  }
 
   // backward through the critic to the action only (critic weight grads are never used: SURVEY A7(iii))
   {
@@ -444,7 +457,7 @@ int check_step(const DrqStep* s) {
 
 extern "C" {
 
-int drq_abi_version(void) { return 1; }
+int drq_abi_version(void) { return 2; }
 
 int drq_param_layout(int C, int A, int F, int H, long* out, int cap) {
   if (!out || cap < DRQ_PARAM_LAYOUT_LEN || C <= 0 || A <= 0 || F <= 0 || H <= 0) return DRQ_EARG;

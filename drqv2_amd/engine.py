@@ -94,6 +94,10 @@ class StepEngine:
         self._ws_B = None
         self._base = None
         self.sums = torch.zeros(8, device=dev, dtype=torch.float32)
+        # pinned host mirror of the metric sums (DrqStep.sums_host): slot 8 = sequence word of the update
+        self.sums_host = torch.zeros(16, dtype=torch.float32).pin_memory() if dev.type == "cuda" else None
+        self._sums_seq = self.sums_host[8:9].view(torch.int32) if self.sums_host is not None else None
+        self._last_seq = None
         self.pg = None            # torch.distributed process group for data parallelism
         self.world = 1
         self.rank = 0
@@ -171,6 +175,7 @@ class StepEngine:
         # all-reduce over ranks yields the global-batch mean gradient: no further scaling
         d.gscale = 1.0
         d.stream = torch.cuda.current_stream().cuda_stream
+        d.sums_host = ptr(self.sums_host) if (self.world == 1 and self.sums_host is not None) else None
         return d
 
     def update(self, obs, action, reward, discount, next_obs, shift_obs, shift_next, noise_critic, noise_actor, std,
@@ -189,7 +194,9 @@ class StepEngine:
         ref = ctypes.byref(d)
         if self.world == 1:
             check(lib.drq_update_phase(ref, -1), "drq_update_phase")
+            self._last_seq = steps[2] & 0xFFFFFFFF
         else:
+            self._last_seq = None
             b1, b2 = grad_buckets(self.layout)
             check(lib.drq_update_phase(ref, 0), "drq_update_phase(0)")
             self._allreduce(self.grads[b1[0]:b1[1]])      # bucket 1: encoder + critic
@@ -199,6 +206,26 @@ class StepEngine:
             check(lib.drq_update_phase(ref, 2), "drq_update_phase(2)")
         del keep
         return self.sums
+
+    def read_sums(self):
+        """The 8 metric sums of the last update as Python floats.  Single GPU: waits only until the update has
+        published them (after the actor loss), not for the rest of the update still queued behind it."""
+        if self._last_seq is None:
+            return self.sums.tolist()                      # data parallel: reduced on the device, drain the stream
+        want = self._last_seq if self._last_seq < 2 ** 31 else self._last_seq - 2 ** 32
+        seq = self._sums_seq
+        t0 = None
+        spins = 0
+        while int(seq) != want:
+            spins += 1
+            if spins % 4096 == 0:
+                import time
+                t0 = t0 or time.monotonic()
+                if time.monotonic() - t0 > 30.0:
+                    torch.cuda.synchronize()               # surfaces a device fault, if that is why nothing arrived
+                    if int(seq) != want:
+                        raise _lib.DrqError("metric sums of the update never arrived in the host mirror")
+        return self.sums_host[:8].tolist()
 
     def act_forward(self, obs_u8):
         """obs u8 [n,C,84,84] on the GPU -> mu [n,A]."""

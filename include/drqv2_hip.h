@@ -143,6 +143,13 @@ typedef struct {
   long step_critic, step_enc, step_actor; /* 1-based Adam step numbers of THIS update */
   float gscale;              /* 1/world_size when gradients were SUM-reduced, else 1 */
   drq_stream_t stream;
+  float* sums_host;          /* optional (may be NULL): device-visible pinned host memory, 16 floats.  As soon as
+                              * sums[0..7] are final (after the actor loss, BEFORE the actor backward / Adam /
+                              * Polyak tail of the update) phase 1 writes them to sums_host[0..7], then stores the
+                              * 32-bit value (uint32_t)step_actor in slot 8 with system-scope release.  The host
+                              * reads the metrics (drqv2.py:191-198,218-223: the .item() calls) by polling slot 8
+                              * instead of draining the stream.  Single-GPU only: with data parallelism the sums
+                              * are partial until the host has all-reduced them. */
 } DrqStep;
 
 /* Parameter arena: tensors in parameters() order of encoder, critic, actor, critic_target, each start
