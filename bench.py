@@ -173,7 +173,12 @@ def cpu_baseline(task, B):
     from drqv2_amd import synth
     from oracle import drq_oracle as O
     A, F, lr, sched = TASKS[task]
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the GPU box gives one GPU's job a 16-core share of a much larger host: more threads than that thrash
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(16, ncpu)))
     enc, actor, critic = synth.make_weights(9, A, F, 1024, 0)
     ag = O.OracleAgent(enc, actor, critic, lr, stddev_schedule=sched)
     batch = synth.make_batch(B, A, 9, seed=0, smooth=True)

@@ -860,13 +860,13 @@ int launch_conv_v(const ConvArgs& a, hipStream_t st) {
 }
 
 // DRQ_CONV_VARIANT (development knob, read once): timing ablations of the forward kernel
+int g_conv_variant = -1;          // drq_dev_conv_variant (undeclared development hook) overrides the env var
 inline int conv_variant() {
-  static int v = -1;
-  if (v < 0) {
+  if (g_conv_variant < 0) {
     const char* e = getenv("DRQ_CONV_VARIANT");
-    v = e ? atoi(e) : 0;
+    g_conv_variant = e ? atoi(e) : 0;
   }
-  return v;
+  return g_conv_variant;
 }
 
 template <int CIN, int HIN, int STRIDE>
@@ -972,6 +972,7 @@ extern "C" {
 
 // development hook (not part of the ABI): device buffer of 32 u64 per wave for DRQ_CONV_VARIANT=10
 void drq_dev_conv_stamps(void* p) { g_conv_stamps = (unsigned long long*)p; }
+void drq_dev_conv_variant(int v) { g_conv_variant = v; }
 
 // y = relu?(conv3x3(x, w) + bias); x [nb][cin][hin][hin], y written with the given strides.
 int drq_conv3x3_fwd(const float* x, const float* w, const float* bias, float* y, int nb, int cin, int hin,
