@@ -43,6 +43,11 @@ def alg_flops_per_update(B, A, F, H=1024):
 
 
 def main():
+    # stdout carries exactly one JSON line: anything else that writes to fd 1 (RCCL prints a version banner
+    # there at init, libdrm complains about amdgpu.ids) is sent to stderr, the line goes out on a private dup.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -52,6 +57,8 @@ def main():
     ap.add_argument("--strong", action="store_true", help="split ONE --batch over the GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dp-schedule", action="store_true",
+                    help="development: run the data-parallel schedule on a one-rank RCCL group (N=1 only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -62,9 +69,11 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dp = world > 1 or args.dp_schedule
+    if use_dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import drqv2
@@ -76,7 +85,7 @@ def main():
     B_global = B_local * world
     torch.manual_seed(1)
     agent = drqv2.DrQV2Agent((9, 84, 84), (A,), dev, lr, F, H, 0.01, 2000, 2, sched, 0.3, True)
-    if world > 1:
+    if use_dp:
         agent.enable_data_parallel(batch_is_global=False)
     batch = tuple(t.to(dev) for t in synth.make_batch(B_local, A, 9, seed=rank, smooth=True))
 
@@ -89,6 +98,7 @@ def main():
     for _ in range(args.warmup):
         agent.update(it, step)
         step += 2
+    agent.flush()
 
     def sync():
         if world > 1:
@@ -100,6 +110,7 @@ def main():
     for _ in range(args.steps):
         metrics = agent.update(it, step)
         step += 2
+    agent.flush()          # data parallel: the last update's deferred Adam(actor) belongs to the timed region
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -127,9 +138,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.task, B_local)
     if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
+        print(json.dumps(out), file=json_out, flush=True)
+    if use_dp:
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
 
 

@@ -163,10 +163,12 @@ class DrQV2Agent:
         return action.cpu().numpy()[0]
 
     # ---- data parallel (new: one process per GPU, RCCL all-reduce of the flat gradient arenas) ---
-    def enable_data_parallel(self, process_group=None, batch_is_global=True):
+    def enable_data_parallel(self, process_group=None, batch_is_global=True, global_metrics=False):
         """batch_is_global: every rank's replay_iter yields the same global batch and this rank trains
-        on its contiguous slice; otherwise the iterator already yields this rank's shard."""
-        self._engine.enable_data_parallel(process_group)
+        on its contiguous slice; otherwise the iterator already yields this rank's shard.
+        global_metrics: the returned metrics are means over the GLOBAL batch (one more 32-byte all-reduce per
+        update); by default they are the means over this rank's shard (the gradients are always global)."""
+        self._engine.enable_data_parallel(process_group, global_metrics)
         self._batch_is_global = batch_is_global
 
     def _draws(self, n_global, A):
@@ -208,7 +210,8 @@ class DrQV2Agent:
 
         if self.use_tb:
             s = eng.read_sums()          # the single device->host wait of the update
-            inv = 1.0 / n_global
+            # data parallel without global_metrics: the sums cover this rank's rows only
+            inv = 1.0 / (n_global if (eng.pg is None or eng.global_metrics) else (hi - lo))
             metrics["batch_reward"] = s[0] * inv
             metrics["critic_target_q"] = s[1] * inv
             metrics["critic_q1"] = s[2] * inv
@@ -220,7 +223,14 @@ class DrQV2Agent:
         return metrics
 
     # ---- snapshots: train.py:192-204 pickles the whole agent --------------------------------
+    def flush(self):
+        """Data parallel only: finish the Adam(actor) step the last update() left overlapped with its gradient
+        all-reduce.  update(), act() and snapshots do this themselves; call it before reading actor weights
+        directly."""
+        self._engine.flush()
+
     def __getstate__(self):
+        self._engine.flush()
         cpu = lambda sd: {k: v.detach().cpu().clone() for k, v in sd.items()}
         return {"init": self._init_kwargs, "training": self.training,
                 "encoder": cpu(self.encoder.state_dict()), "actor": cpu(self.actor.state_dict()),

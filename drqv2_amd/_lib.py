@@ -66,6 +66,7 @@ PROTOTYPES = {
     "drq_step_ws_offset": (L, [I, I, I, I, I, I]),
     "drq_update_phase": (I, [C.POINTER(DrqStep), I]),
     "drq_act_forward": (I, [C.POINTER(DrqStep), P, I, P]),
+    "drq_publish_sums": (I, [P, P, C.c_uint, P]),
 }
 
 WS_IDS = ["AUG", "ACT1", "ACT2", "ACT3", "FEAT", "Z_NEXT", "Z_OBS", "HA_T", "HA_C", "H_AN", "H_AO", "Q", "TQ",

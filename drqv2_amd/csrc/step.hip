@@ -236,24 +236,33 @@ int q_forward(const Ctx& c, int nn, const HeadOff* const* nets, const float* con
   return 0;
 }
 
-// ---- phase 0 ---------------------------------------------------------------------------------
-int phase_critic(const Ctx& c) {
+// ---- phase 0 = phases 3, 4, 5 -------------------------------------------------------------------
+// phase 3: augmentation + encoder forward (reads encoder weights only)
+int phase_encode(const Ctx& c) {
   const DrqStep* s = c.s;
-  const ParamLayout& P = c.P;
-  const int B = s->B, C = s->C, A = s->A, F = s->F, H = s->H, FA = F + A;
+  const int B = s->B, C = s->C;
   hipStream_t st = c.st;
   float* aug = c.ws(W_AUG);
+  // aug (drqv2.py:241-242) + /255-0.5 (:64); rows [0,B) = obs, [B,2B) = next_obs
+  CK(drq_aug_fwd(s->obs, s->shift_obs, s->base_grid, aug, B, C, 84, 4, 1, st));
+  CK(drq_aug_fwd(s->next_obs, s->shift_next, s->base_grid, aug + (long)B * C * 84 * 84, B, C, 84, 4, 1, st));
+  // encoder on both views in one pass (:244-246)
+  CK(encoder_forward(c, aug, 2 * B, c.ws(W_ACT1), c.ws(W_ACT2), c.ws(W_ACT3), c.ws(W_FEAT)));
+  return 0;
+}
+
+// phase 4: trunks, policy, Q heads, TD loss and its backward down to the encoder output
+// (leaves ALL critic gradients and sums[0..4]; reads actor, critic and target weights)
+int phase_critic_heads(const Ctx& c) {
+  const DrqStep* s = c.s;
+  const ParamLayout& P = c.P;
+  const int B = s->B, A = s->A, F = s->F, H = s->H, FA = F + A;
+  hipStream_t st = c.st;
   float* feat = c.ws(W_FEAT);
   float* feat_obs = feat;
   float* feat_next = feat + (long)B * R;
   const HeadOff &cr = P.critic, &ac = P.actor, &tg = P.target;
   const long BH = (long)B * H;
-
-  // aug (drqv2.py:241-242) + /255-0.5 (:64); rows [0,B) = obs, [B,2B) = next_obs
-  CK(drq_aug_fwd(s->obs, s->shift_obs, s->base_grid, aug, B, C, 84, 4, 1, st));
-  CK(drq_aug_fwd(s->next_obs, s->shift_next, s->base_grid, aug + (long)B * C * 84 * 84, B, C, 84, 4, 1, st));
-  // encoder on both views in one pass (:244-246)
-  CK(encoder_forward(c, aug, 2 * B, c.ws(W_ACT1), c.ws(W_ACT2), c.ws(W_ACT3), feat));
 
   // all four trunks in one launch: critic(obs), actor(obs), actor(next), target(next).  actor(obs) is needed
   // only by the actor step; the actor's weights do not change before that, so it is evaluated here.
@@ -328,7 +337,15 @@ int phase_critic(const Ctx& c) {
                             c.gemm_ws(), c.gemm_ws_bytes(), st));
   }
 
-  // ---- encoder backward: conv4 .. conv1 (wgrad all, dgrad 4..2)
+  return 0;
+}
+
+// phase 5: encoder backward, conv4 .. conv1 (wgrad all, dgrad 4..2): leaves the encoder gradients
+int phase_conv_backward(const Ctx& c) {
+  const DrqStep* s = c.s;
+  const ParamLayout& P = c.P;
+  const int B = s->B, C = s->C;
+  hipStream_t st = c.st;
   const int dyid[4] = {W_DY1, W_DY2, W_DY3, W_DY4};
   const int actid[4] = {W_AUG, W_ACT1, W_ACT2, W_ACT3};   // layer inputs
   float* cws = c.ws(W_CONV_WS);
@@ -356,20 +373,28 @@ __global__ void publish_sums_kernel(const float* sums, float* host, unsigned seq
   if (threadIdx.x == 0) __hip_atomic_store((unsigned*)(host + 8), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-int phase_actor(const Ctx& c) {
+int publish_sums(const float* sums, float* sums_host, unsigned seq, hipStream_t st) {
+  if (!sums || !sums_host) return DRQ_EARG;
+  hipLaunchKernelGGL(publish_sums_kernel, dim3(1), dim3(64), 0, st, sums, sums_host, seq);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
+// ---- phase 1 = phases 6, 7 ------------------------------------------------------------------------
+// phase 6: critic_opt.step() (:201) + Polyak (:259-260, fused: it reads the stepped critic; nothing between here
+// and the end of the update reads the target), then the actor loss through the UPDATED critic (:210-216).
+// encoder_opt.step() (:202) is phase 8: the actor update works on obs.detach() encoded BEFORE that step
+// (:255), so nothing in phases 6/7 reads the encoder weights and the step commutes to the end of the update.
+int phase_actor_forward(const Ctx& c) {
   const DrqStep* s = c.s;
   const ParamLayout& P = c.P;
-  const int B = s->B, A = s->A, F = s->F, H = s->H, FA = F + A;
+  const int B = s->B, A = s->A, F = s->F, FA = F + A;
   hipStream_t st = c.st;
   float* feat_obs = c.ws(W_FEAT);
-  const HeadOff &cr = P.critic, &ac = P.actor;
-  const long BH = (long)B * H;
+  const HeadOff& cr = P.critic;
 
-  // critic_opt.step(); encoder_opt.step() (:201-202) + Polyak (:259-260, fused: it reads the stepped critic)
   CK(drq_adam_flat(c.p(P.seg[2]), c.g(P.seg[2]), s->adam_m + P.seg[2], s->adam_v + P.seg[2], P.seg[3] - P.seg[2],
                    s->lr, s->step_critic, s->gscale, c.p(P.seg[6]), s->tau, st));
-  CK(drq_adam_flat(c.p(P.seg[0]), c.g(P.seg[0]), s->adam_m + P.seg[0], s->adam_v + P.seg[0], P.seg[1] - P.seg[0],
-                   s->lr, s->step_enc, s->gscale, nullptr, 0.0, st));
 
   // a ~ TruncN(actor(obs.detach())) (:210-211): the policy MLP output for the obs rows was computed in phase 0
   CK(drq_trunc_normal_sample(c.ws(W_P3), s->noise_actor, s->std, s->clip, 1, c.ws(W_MU_O), c.ws(W_HA_C2) + F, FA, B,
@@ -390,11 +415,19 @@ int phase_actor(const Ctx& c) {
   const float invB = 1.0f / (float)s->global_B;
   CK(drq_actor_loss(c.ws(W_TQ), c.ws(W_TQ) + B, c.ws(W_HA_C2) + F, FA, c.ws(W_MU_O), s->std, c.ws(W_DQ),
                     c.ws(W_DQ) + B, s->sums, B, A, invB, st));
-  if (s->sums_host) {
-    hipLaunchKernelGGL(publish_sums_kernel, dim3(1), dim3(64), 0, st, (const float*)s->sums, s->sums_host,
-                       (unsigned)s->step_actor);
-    DRQ_LAUNCH_CHECK();
-  }
+  if (s->sums_host) CK(publish_sums(s->sums, s->sums_host, (unsigned)s->step_actor, st));
+  return 0;
+}
+
+// phase 7: backward of the actor loss (:218-221) -> actor gradients
+int phase_actor_backward(const Ctx& c) {
+  const DrqStep* s = c.s;
+  const ParamLayout& P = c.P;
+  const int B = s->B, A = s->A, F = s->F, H = s->H, FA = F + A;
+  hipStream_t st = c.st;
+  float* feat_obs = c.ws(W_FEAT);
+  const HeadOff &cr = P.critic, &ac = P.actor;
+  const long BH = (long)B * H;
 
   // backward through the critic to the action only (critic weight grads are never used: SURVEY A7(iii))
   {
@@ -436,7 +469,15 @@ int phase_actor(const Ctx& c) {
   return 0;
 }
 
-int phase_actor_opt(const Ctx& c) {
+// ---- phase 2 = phases 8, 9 ------------------------------------------------------------------------
+int phase_encoder_opt(const Ctx& c) {   // encoder_opt.step() (:202)
+  const DrqStep* s = c.s;
+  const ParamLayout& P = c.P;
+  return drq_adam_flat(c.p(P.seg[0]), c.g(P.seg[0]), s->adam_m + P.seg[0], s->adam_v + P.seg[0], P.seg[1] - P.seg[0],
+                       s->lr, s->step_enc, s->gscale, nullptr, 0.0, c.st);
+}
+
+int phase_actor_opt(const Ctx& c) {     // actor_opt.step() (:221)
   const DrqStep* s = c.s;
   const ParamLayout& P = c.P;
   return drq_adam_flat(c.p(P.seg[4]), c.g(P.seg[4]), s->adam_m + P.seg[4], s->adam_v + P.seg[4], P.seg[5] - P.seg[4],
@@ -485,11 +526,19 @@ int drq_update_phase(const DrqStep* s, int phase) {
       !s->noise_critic || !s->noise_actor || !s->base_grid || !s->grads || !s->adam_m || !s->adam_v || !s->sums)
     return DRQ_EARG;
   Ctx c{s, param_layout(s->C, s->A, s->F, s->H), ws_layout(s->B, s->C, s->A, s->F, s->H), (hipStream_t)s->stream};
-  if (phase == 0 || phase == -1) CK(phase_critic(c));
-  if (phase == 1 || phase == -1) CK(phase_actor(c));
-  if (phase == 2 || phase == -1) CK(phase_actor_opt(c));
-  if (phase < -1 || phase > 2) return DRQ_EARG;
+  if (phase < -1 || phase > 9) return DRQ_EARG;
+  if (phase == 3 || phase == 0 || phase == -1) CK(phase_encode(c));
+  if (phase == 4 || phase == 0 || phase == -1) CK(phase_critic_heads(c));
+  if (phase == 5 || phase == 0 || phase == -1) CK(phase_conv_backward(c));
+  if (phase == 6 || phase == 1 || phase == -1) CK(phase_actor_forward(c));
+  if (phase == 7 || phase == 1 || phase == -1) CK(phase_actor_backward(c));
+  if (phase == 8 || phase == 2 || phase == -1) CK(phase_encoder_opt(c));
+  if (phase == 9 || phase == 2 || phase == -1) CK(phase_actor_opt(c));
   return 0;
+}
+
+int drq_publish_sums(const float* sums, float* sums_host, unsigned seq, drq_stream_t stream) {
+  return publish_sums(sums, sums_host, seq, (hipStream_t)stream);
 }
 
 int drq_act_forward(const DrqStep* s, const uint8_t* obs, int n, float* mu_out) {

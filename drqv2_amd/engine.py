@@ -63,10 +63,18 @@ def shard_bounds(n_rows, world, rank, batch_is_global):
 
 
 def grad_buckets(layout):
-    """The two all-reduce buckets of one update as [beg,end) ranges of the gradient arena:
+    """The two dependent exchanges of one update as [beg,end) ranges of the gradient arena:
     (encoder+critic) after the critic backward, (actor) after the actor backward."""
     seg = layout["seg"]
     return (seg["enc"][0], seg["critic"][1]), (seg["actor"][0], seg["actor"][1])
+
+
+def grad_buckets_overlap(layout):
+    """The same exchanges as the overlapped schedule issues them: critic (complete before the encoder
+    backward starts, reduced while it runs), encoder (tiny, after it), actor (reduced while the NEXT update's
+    encoder forward runs)."""
+    seg = layout["seg"]
+    return tuple((seg[k][0], seg[k][1]) for k in ("critic", "enc", "actor"))
 
 
 class StepEngine:
@@ -99,6 +107,11 @@ class StepEngine:
         self._sums_seq = self.sums_host[8:9].view(torch.int32) if self.sums_host is not None else None
         self._last_seq = None
         self.pg = None            # torch.distributed process group for data parallelism
+        self._pending = None      # (all-reduce handle, descriptor, tensors kept alive) of a deferred Adam(actor)
+        self._pending_enc = None  # the same for Adam(encoder)
+        self.global_metrics = False   # data parallel: all-reduce the metric sums (else: this rank's shard)
+        self._side = None         # side stream of the metric-sums exchange
+        self._side_busy = False
         self.world = 1
         self.rank = 0
 
@@ -147,8 +160,9 @@ class StepEngine:
         return self._base
 
     # ---- data parallel -------------------------------------------------------------------
-    def enable_data_parallel(self, process_group=None):
+    def enable_data_parallel(self, process_group=None, global_metrics=False):
         import torch.distributed as dist
+        self.global_metrics = bool(global_metrics)
         self.pg = process_group if process_group is not None else dist.group.WORLD
         self.world = dist.get_world_size(self.pg)
         self.rank = dist.get_rank(self.pg)
@@ -156,6 +170,47 @@ class StepEngine:
     def _allreduce(self, t):
         import torch.distributed as dist
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def _allreduce_async(self, t):
+        """SUM all-reduce that starts once the work queued so far has produced `t` and runs beside what is
+        queued next (RCCL: its own stream; .wait() makes the current stream wait, not the host)."""
+        import torch.distributed as dist
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
+    def _phase(self, desc, k):
+        check(_lib.load().drq_update_phase(ctypes.byref(desc), k), f"drq_update_phase({k})")
+
+    def flush_encoder(self):
+        """Data parallel: the deferred Adam(encoder) of the last update (phase 8).  Before the encoder is read."""
+        if self._pending_enc is None:
+            return
+        work, desc, keep = self._pending_enc
+        self._pending_enc = None
+        work.wait()
+        if self.device.type == "cuda":
+            desc.stream = torch.cuda.current_stream().cuda_stream
+        self._phase(desc, 8)
+        del keep
+
+    def flush(self):
+        """Data parallel: complete the deferred Adam(encoder) and Adam(actor) of the last update (their gradient
+        all-reduces were left running).  Called before anything reads those weights: the next update, act(),
+        snapshots."""
+        self.flush_encoder()
+        if self._pending is None:
+            return
+        work, desc, keep = self._pending
+        self._pending = None
+        work.wait()
+        if self.device.type == "cuda":
+            desc.stream = torch.cuda.current_stream().cuda_stream
+        self._phase(desc, 9)
+        del keep
 
     # ---- the step ------------------------------------------------------------------------
     def make_desc(self, B_local, B_global, std, clip, tau, steps):
@@ -175,13 +230,12 @@ class StepEngine:
         # all-reduce over ranks yields the global-batch mean gradient: no further scaling
         d.gscale = 1.0
         d.stream = torch.cuda.current_stream().cuda_stream
-        d.sums_host = ptr(self.sums_host) if (self.world == 1 and self.sums_host is not None) else None
+        d.sums_host = ptr(self.sums_host) if (self.pg is None and self.sums_host is not None) else None
         return d
 
     def update(self, obs, action, reward, discount, next_obs, shift_obs, shift_next, noise_critic, noise_actor, std,
                clip, tau, B_global=None):
         """All tensors are this rank's shard, on the GPU.  Returns the 8-float sums tensor (device)."""
-        lib = _lib.load()
         B = obs.shape[0]
         B_global = B * self.world if B_global is None else B_global
         steps = (self.critic_opt.begin_step(), self.encoder_opt.begin_step(), self.actor_opt.begin_step())
@@ -191,19 +245,54 @@ class StepEngine:
         d.action, d.reward, d.discount = ptr(action), ptr(reward), ptr(discount)
         d.shift_obs, d.shift_next = ptr(shift_obs), ptr(shift_next)
         d.noise_critic, d.noise_actor = ptr(noise_critic), ptr(noise_actor)
-        ref = ctypes.byref(d)
-        if self.world == 1:
-            check(lib.drq_update_phase(ref, -1), "drq_update_phase")
+        if self.pg is None:
+            self._phase(d, -1)
             self._last_seq = steps[2] & 0xFFFFFFFF
         else:
-            self._last_seq = None
-            b1, b2 = grad_buckets(self.layout)
-            check(lib.drq_update_phase(ref, 0), "drq_update_phase(0)")
-            self._allreduce(self.grads[b1[0]:b1[1]])      # bucket 1: encoder + critic
-            check(lib.drq_update_phase(ref, 1), "drq_update_phase(1)")
-            self._allreduce(self.grads[b2[0]:b2[1]])      # bucket 2: actor
-            self._allreduce(self.sums)
-            check(lib.drq_update_phase(ref, 2), "drq_update_phase(2)")
+            # overlapped schedule.  Every exchange is a SUM of gradients already scaled by
+            # 1/global_B; the order of the phases and their data dependencies are those of the 1-GPU step.
+            # Every event recorded on the compute stream costs it a ~20 us bubble (system-scope release), so
+            # the schedule hands over to RCCL only twice: after phase 4 and after phase 7.
+            (c0, c1), (e0, e1), (a0, a1) = grad_buckets_overlap(self.layout)
+            mirror = self.sums_host is not None
+            seq = steps[2] & 0xFFFFFFFF
+            if self._side_busy:                                 # the previous update's sums exchange owns self.sums
+                torch.cuda.current_stream().wait_stream(self._side)
+                self._side_busy = False
+            self.flush_encoder()                                # previous update's Adam(encoder)
+            self._phase(d, 3)                                   # aug + encoder forward: no actor weights yet
+            self.flush()                                        # previous update's Adam(actor), reduce done by now
+            self._phase(d, 4)                                   # critic loss, backward to the encoder output
+            w_critic = self._allreduce_async(self.grads[c0:c1])  # 16.7 MB, under the encoder backward
+            self._phase(d, 5)
+            w_critic.wait()
+            if not self.global_metrics:
+                # metrics of THIS rank's shard (means over its rows): published by phase 6 itself, no exchange
+                d.sums_host = ptr(self.sums_host) if mirror else None
+                self._phase(d, 6)                               # Adam(critic), actor loss (sums complete)
+                self._last_seq = seq if mirror else None
+            else:
+                self._phase(d, 6)
+                # global metric sums: reduced and published beside phase 7 (a side stream, so that the 32-byte
+                # exchange's latency is not inserted between phases 6 and 7)
+                if self.device.type == "cuda":
+                    main = torch.cuda.current_stream()
+                    side = self._side_stream()
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        self._allreduce_async(self.sums).wait()
+                        if mirror:
+                            check(_lib.load().drq_publish_sums(ptr(self.sums), ptr(self.sums_host), seq,
+                                                               side.cuda_stream), "drq_publish_sums")
+                    self._side_busy = True
+                    self._last_seq = seq if mirror else None
+                else:
+                    self._allreduce_async(self.sums).wait()
+                    self._last_seq = None
+            self._phase(d, 7)                                   # actor backward
+            # encoder (0.1 MB) and actor (12.3 MB) gradients: reduced under the next update's encoder forward
+            self._pending_enc = (self._allreduce_async(self.grads[e0:e1]), d, keep)
+            self._pending = (self._allreduce_async(self.grads[a0:a1]), d, keep)
         del keep
         return self.sums
 
@@ -211,7 +300,9 @@ class StepEngine:
         """The 8 metric sums of the last update as Python floats.  Single GPU: waits only until the update has
         published them (after the actor loss), not for the rest of the update still queued behind it."""
         if self._last_seq is None:
-            return self.sums.tolist()                      # data parallel: reduced on the device, drain the stream
+            if self._side_busy:
+                self._side.synchronize()
+            return self.sums.tolist()                      # no host mirror: drain the stream
         want = self._last_seq if self._last_seq < 2 ** 31 else self._last_seq - 2 ** 32
         seq = self._sums_seq
         t0 = None
@@ -229,6 +320,7 @@ class StepEngine:
 
     def act_forward(self, obs_u8):
         """obs u8 [n,C,84,84] on the GPU -> mu [n,A]."""
+        self.flush()
         lib = _lib.load()
         n = obs_u8.shape[0]
         B = self._ws_B if (self._ws_B is not None and 2 * self._ws_B >= n) else max(1, (n + 1) // 2)

@@ -168,11 +168,25 @@ enum {
   DRQ_WS_DY4, DRQ_WS_DY3, DRQ_WS_DY2, DRQ_WS_DY1, DRQ_WS_DZ_C, DRQ_WS_DZ_A, DRQ_WS_HA_C2, DRQ_WS_NBUF_PUBLIC
 };
 
-/* phase 0: aug, encoder fwd, critic loss + backward  (leaves encoder+critic grads, sums[0..4])
- * phase 1: Adam(critic)+Polyak, Adam(encoder), actor loss + backward (actor grads, sums[5..6])
- * phase 2: Adam(actor)
- * phase -1: all three back to back (single GPU).  The data-parallel host all-reduces between phases. */
+/* One update = phases 3..9 in this order (phase -1 runs them all: single GPU):
+ *   3  aug + encoder forward (drqv2.py:241-246)         reads the encoder weights only
+ *   4  trunks, policy, Q heads, TD loss, backward down to the encoder output (:180-200)
+ *      leaves ALL critic gradients and sums[0..4]; first reader of the actor weights
+ *   5  encoder backward                                  leaves the encoder gradients
+ *   6  Adam(critic) + Polyak (:201,:259-260), actor loss through the updated critic (:210-216)
+ *      leaves sums[5..6]; publishes sums to sums_host when that is set
+ *   7  actor backward (:218-220)                         leaves the actor gradients
+ *   8  Adam(encoder) (:202)   commutes to here: phases 6/7 work on features encoded before it (:255)
+ *   9  Adam(actor) (:221)
+ * Composite ids kept for callers that exchange at coarser points: 0 = 3,4,5; 1 = 6,7; 2 = 8,9.
+ * A data-parallel host SUM-all-reduces the critic gradients while 5 runs, the encoder gradients while 6/7 run,
+ * the metric sums after 6 and the actor gradients after 7; 8 may be deferred until the next update's phase 3
+ * and 9 until its phase 4 (or drq_act_forward), so both exchanges overlap compute. */
 int drq_update_phase(const DrqStep* s, int phase);
+
+/* sums[0..7] -> sums_host[0..7], then seq -> slot 8 with system-scope release (see DrqStep.sums_host); for hosts
+ * that reduce the sums themselves before publishing them. */
+int drq_publish_sums(const float* sums, float* sums_host, unsigned seq, drq_stream_t stream);
 
 /* Encoder+actor forward for DrQV2Agent.act (drqv2.py:164-175): obs u8 [n][C][84][84] -> mu [n][A]
  * (n <= 2*B; uses s->params, s->ws, s->stream only; must not run between the phases of an update). */

@@ -45,7 +45,7 @@ def _worker(rank, world, port, ret):
         torch.set_num_threads(2)
         from oracle import drq_oracle as O
         from drqv2_amd import _lib
-        from drqv2_amd.engine import grad_buckets, shard_bounds
+        from drqv2_amd.engine import grad_buckets, grad_buckets_overlap, shard_bounds
         full, m_full, (enc, actor, critic), batch, draws = _full_batch_reference()
         lay = _lib.param_layout(CFG["C"], CFG["A"], CFG["F"], CFG["H"])
         lo, hi, n_global = shard_bounds(CFG["B"], world, rank, True)
@@ -67,6 +67,8 @@ def _worker(rank, world, port, ret):
         put("critic", local["g_critic"])
         b1, b2 = grad_buckets(lay)
         assert b1 == (lay["seg"]["enc"][0], lay["seg"]["critic"][1]) and b1[1] <= b2[0]
+        cb, eb, ab = grad_buckets_overlap(lay)      # the overlapped schedule splits bucket 1 at the enc/critic seam
+        assert (eb[0], cb[1]) == b1 and eb[1] <= cb[0] and ab == b2
         dist.all_reduce(grads[b1[0]:b1[1]], op=dist.ReduceOp.SUM)
         for net, key in (("enc", "g_enc"), ("critic", "g_critic")):
             for off, g in zip(lay[net], full.last[key].values()):
@@ -107,6 +109,72 @@ def test_two_rank_sharded_update_equals_full_batch():
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     assert dict(ret) == {0: "ok", 1: "ok"}
+
+
+def test_overlapped_schedule_order_and_deferred_actor_step():
+    """Host logic of the overlapped data-parallel schedule (drqv2_amd.engine.StepEngine.update): phase order,
+    which arena range each exchange covers, and that Adam(encoder) / Adam(actor) (phases 8 / 9) of update k
+    run in update k+1 just before their weights are first read, or at flush()/act()/snapshot time.  No GPU: phases and collectives are recorded."""
+    import drqv2
+    from drqv2_amd.engine import grad_buckets_overlap
+    ag = drqv2.DrQV2Agent((9, 84, 84), (3,), "cpu", 1e-3, 20, 64, 0.01, 2000, 2, "0.2", 0.3, False)
+    eng = ag._engine
+    log = []
+
+    class Work:
+        def __init__(self, name):
+            self.name = name
+
+        def wait(self):
+            log.append(("wait", self.name))
+
+    def fake_async(t):
+        off = (t.data_ptr() - eng.grads.data_ptr()) // 4 if t.data_ptr() != eng.sums.data_ptr() else -1
+        name = "sums" if off < 0 else (off, off + t.numel())
+        log.append(("allreduce", name))
+        return Work(name)
+
+    eng.pg, eng.world, eng.rank = object(), 2, 0
+    eng._allreduce_async = fake_async
+    eng._phase = lambda d, k: log.append(("phase", k, int(d.step_actor)))
+    # the real descriptor builder needs a GPU: a minimal one stands in
+    import types
+    from drqv2_amd._lib import DrqStep
+
+    def make_desc(self, B_local, B_global, std, clip, tau, steps):
+        d = DrqStep()
+        d.B, d.global_B = B_local, B_global
+        d.step_critic, d.step_enc, d.step_actor = steps
+        return d
+    eng.make_desc = types.MethodType(make_desc, eng)
+    batch = synth.make_batch(4, 3)
+    draws = synth.make_draws(8, 3, seed=1)
+    args = list(batch) + [t[:4] for t in draws]
+    crit, enc, act = grad_buckets_overlap(eng.layout)
+    eng.update(*args, 0.2, 0.3, 0.01, B_global=8)
+    # default: shard-local metrics -> two hand-overs to the collective library per update
+    assert log == [("phase", 3, 1), ("phase", 4, 1), ("allreduce", crit), ("phase", 5, 1), ("wait", crit),
+                   ("phase", 6, 1), ("phase", 7, 1), ("allreduce", enc), ("allreduce", act)]
+    assert eng._pending is not None and eng._pending_enc is not None
+    del log[:]
+    eng.global_metrics = True
+    eng.update(*args, 0.2, 0.3, 0.01, B_global=8)
+    # the deferred steps of update 1 (step numbers 1): Adam(encoder) before phase 3, Adam(actor) before phase 4
+    assert log[:6] == [("wait", enc), ("phase", 8, 1), ("phase", 3, 2), ("wait", act), ("phase", 9, 1),
+                       ("phase", 4, 2)]
+    # global metrics: the sums are exchanged between phases 6 and 7
+    assert log[6:] == [("allreduce", crit), ("phase", 5, 2), ("wait", crit), ("phase", 6, 2), ("allreduce", "sums"),
+                       ("wait", "sums"), ("phase", 7, 2), ("allreduce", enc), ("allreduce", act)]
+    del log[:]
+    ag.flush()
+    assert log == [("wait", enc), ("phase", 8, 2), ("wait", act), ("phase", 9, 2)]
+    assert eng._pending is None and eng._pending_enc is None
+    ag.flush()
+    assert len(log) == 4                                      # idempotent
+    # the three ranges tile [enc_beg, actor_end) of the arena exactly
+    seg = eng.layout["seg"]
+    assert enc == tuple(seg["enc"]) and crit == tuple(seg["critic"]) and act == tuple(seg["actor"])
+    assert enc[1] <= crit[0] and crit[1] <= act[0]
 
 
 def test_shard_bounds():

@@ -249,3 +249,45 @@ def test_run_to_run_bit_stable():
         mb, _, _ = run_hip(b, cfg, u)
         assert ma == mb
     assert torch.equal(a._engine.params, b._engine.params)
+
+
+def test_overlapped_data_parallel_schedule_equals_single_pass():
+    """The data-parallel schedule (phases 3,4,5,1 with the all-reduces between them and Adam(actor) deferred
+    into the next update) on a ONE-rank RCCL group must be bit-identical to the single drq_update_phase(-1)
+    call: every SUM over one rank is the identity, so only the phase split, the stream hand-offs to RCCL's
+    stream and the deferred step are exercised.  (N>1 ranks need N GPUs: the driver's scaling run.)"""
+    import socket
+    import torch.distributed as dist
+    cfg = CASES["small_h64_b6"]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        a, b, g = make_agent(cfg), make_agent(cfg), make_agent(cfg)
+        b.enable_data_parallel(batch_is_global=False)
+        g.enable_data_parallel(batch_is_global=False, global_metrics=True)     # + the metric-sums exchange
+        assert b._engine.pg is not None and b._engine.world == 1
+        for u in range(3):
+            ma, _, _ = run_hip(a, cfg, u)
+            mb, _, _ = run_hip(b, cfg, u)
+            mg, _, _ = run_hip(g, cfg, u)
+            assert ma == mb and ma == mg, u
+            assert b._engine._pending is not None            # Adam(actor) of this update is still deferred
+        g.flush()
+        torch.cuda.synchronize()
+        assert torch.equal(a._engine.params, g._engine.params)
+        # act() must see the stepped actor: it flushes the deferred step first
+        obs = synth.make_batch(1, cfg["A"], cfg["C"], seed=5)[0][0].numpy()
+        xa = a.act(obs, 10 ** 6, True)
+        xb = b.act(obs, 10 ** 6, True)
+        assert b._engine._pending is None
+        assert np.array_equal(xa, xb)
+        torch.cuda.synchronize()
+        assert torch.equal(a._engine.params, b._engine.params)
+        assert torch.equal(a._engine.adam_m, b._engine.adam_m) and torch.equal(a._engine.adam_v, b._engine.adam_v)
+    finally:
+        dist.destroy_process_group()

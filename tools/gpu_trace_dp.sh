@@ -1,0 +1,8 @@
+#!/bin/bash
+# rocprofv3 kernel trace of the bench running the data-parallel schedule on a one-rank RCCL group.  Usage: tools/gpu_trace_dp.sh <tag>
+TAG=${1:-tdp}; OUT=gpurun_out/$TAG; mkdir -p $OUT
+export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --dp-schedule > $OUT/prof_bench.json 2> $OUT/prof.err
+echo "rocprof rc=$?"
+find $OUT/prof -name "*kernel_trace.csv" -exec cp {} $OUT/kernel_trace.csv \;
+python3 tools/trace_summary.py $OUT/kernel_trace.csv > $OUT/timeline.txt; tail -n 5 $OUT/timeline.txt
