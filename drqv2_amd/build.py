@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdrqv2_hip.so")
-SOURCES = ["conv.hip", "gemm.hip", "elementwise.hip", "step.hip"]
+SOURCES = ["conv.hip", "gemm.hip", "gemm2.hip", "skinny.hip", "elementwise.hip", "step.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 

@@ -16,8 +16,7 @@
 
 namespace {
 
-constexpr int BK = 32;
-constexpr int PK = 34;
+constexpr int BK0 = 32;   // k-tile of the default configurations (split-K chunks are multiples of 64: both fit)
 
 constexpr int MAXB = 8;      // problems per launch (same shape, independent pointers)
 
@@ -63,24 +62,26 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, int batch, int
 // mask is applied when the tile is written to LDS (store_tile).  A load behind a per-lane branch, or a
 // select right after it, makes the compiler wait for it at once and serialises the register queue.
 // Requires rows >= 1 and kend > kbeg (checked by the caller).
-template <int BR, bool KC, bool V4>
+template <int BR, bool KC, bool V4, int BK>
 __device__ __forceinline__ void load_tile(const float* P, long ld, int row0, int rows, int k0, int kend,
                                           float (&reg)[BR * BK / 256], int tid) {
   if constexpr (KC && V4) {
-    // 8 threads x float4 along k per row, 32 rows per pass (kend % 4 == 0, kend >= 4)
-    const int r = tid >> 3, kq = (tid & 7) * 4;
+    // BK/4 threads x float4 along k per row, 1024/BK rows per pass (kend % 4 == 0, kend >= 4)
+    constexpr int TPR = BK / 4, RPP = 256 / TPR;
+    const int r = tid / TPR, kq = (tid % TPR) * 4;
     const int kc = min(k0 + kq, kend - 4);
 #pragma unroll
-    for (int p = 0; p < BR / 32; ++p) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(P + (long)min(row0 + p * 32 + r, rows - 1) * ld + kc);
+    for (int p = 0; p < BR / RPP; ++p) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(P + (long)min(row0 + p * RPP + r, rows - 1) * ld + kc);
       reg[p * 4 + 0] = v[0]; reg[p * 4 + 1] = v[1]; reg[p * 4 + 2] = v[2]; reg[p * 4 + 3] = v[3];
     }
   } else if constexpr (KC) {
-    // 32 lanes along k per row, 8 rows per pass
-    const int r = tid >> 5, kk = tid & 31;
+    // BK lanes along k per row, 256/BK rows per pass
+    constexpr int RPP = 256 / BK;
+    const int r = tid / BK, kk = tid % BK;
     const int kc = min(k0 + kk, kend - 1);
 #pragma unroll
-    for (int p = 0; p < BR / 8; ++p) reg[p] = P[(long)min(row0 + p * 8 + r, rows - 1) * ld + kc];
+    for (int p = 0; p < BR / RPP; ++p) reg[p] = P[(long)min(row0 + p * RPP + r, rows - 1) * ld + kc];
   } else {
     // row index contiguous in memory: lanes along rows
     const int r = tid % BR, kk0 = tid / BR;
@@ -92,24 +93,27 @@ __device__ __forceinline__ void load_tile(const float* P, long ld, int row0, int
 }
 
 // registers -> LDS [row][k] (pitch PK), zeroing what lies outside the matrix
-template <int BR, bool KC, bool V4>
+template <int BR, bool KC, bool V4, int BK>
 __device__ __forceinline__ void store_tile(float* S, const float (&reg)[BR * BK / 256], int row0, int rows, int k0,
                                            int kend, int tid) {
+  constexpr int PK = BK + 2;
   if constexpr (KC && V4) {
-    const int r = tid >> 3, kq = (tid & 7) * 4;
+    constexpr int TPR = BK / 4, RPP = 256 / TPR;
+    const int r = tid / TPR, kq = (tid % TPR) * 4;
     const bool kok = k0 + kq < kend;
 #pragma unroll
-    for (int p = 0; p < BR / 32; ++p) {
-      const bool ok = kok && row0 + p * 32 + r < rows;
-      float* d = S + (p * 32 + r) * PK + kq;
+    for (int p = 0; p < BR / RPP; ++p) {
+      const bool ok = kok && row0 + p * RPP + r < rows;
+      float* d = S + (p * RPP + r) * PK + kq;
       d[0] = ok ? reg[p * 4 + 0] : 0.f; d[1] = ok ? reg[p * 4 + 1] : 0.f;
       d[2] = ok ? reg[p * 4 + 2] : 0.f; d[3] = ok ? reg[p * 4 + 3] : 0.f;
     }
   } else if constexpr (KC) {
-    const int r = tid >> 5, kk = tid & 31;
+    constexpr int RPP = 256 / BK;
+    const int r = tid / BK, kk = tid % BK;
     const bool kok = k0 + kk < kend;
 #pragma unroll
-    for (int p = 0; p < BR / 8; ++p) S[(p * 8 + r) * PK + kk] = (kok && row0 + p * 8 + r < rows) ? reg[p] : 0.f;
+    for (int p = 0; p < BR / RPP; ++p) S[(p * RPP + r) * PK + kk] = (kok && row0 + p * RPP + r < rows) ? reg[p] : 0.f;
   } else {
     const int r = tid % BR, kk0 = tid / BR;
     constexpr int KSTEP = 256 / BR;
@@ -121,7 +125,7 @@ __device__ __forceinline__ void store_tile(float* S, const float (&reg)[BR * BK 
 }
 
 // masked sum of this thread's staged A values (row-contiguous layout only): piece of sum_k A(m,k)
-template <int BR>
+template <int BR, int BK>
 __device__ __forceinline__ float tile_rowsum(const float (&reg)[BR * BK / 256], int row0, int rows, int k0, int kend,
                                              int tid) {
   const int r = tid % BR, kk0 = tid / BR;
@@ -135,13 +139,14 @@ __device__ __forceinline__ float tile_rowsum(const float (&reg)[BR * BK / 256], 
   return s;
 }
 
-template <int TM, int TN, bool A_KC, bool B_KC, bool V4>
+template <int TM, int TN, bool A_KC, bool B_KC, bool V4, int BK = BK0>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  constexpr int PK = BK + 2;      // LDS pitch: bank = 2*row + k, conflict-free MFMA operand reads
   constexpr int BM = 32 * TM, BN = 32 * TN;
   constexpr int RA = BM * BK / 256, RB = BN * BK / 256;   // staging registers per thread and k-tile
   // Depth of the register queue of k-tiles in flight from global memory.  Small block tiles do little MFMA
   // work per k-tile (8 MFMAs/wave), so they keep more tiles in flight to cover an L2/HBM round trip.
-  constexpr int D = (TM * TN == 1) ? 4 : 2;
+  constexpr int D = (TM * TN == 1 && BK == 32) ? 4 : 2;
   __shared__ __attribute__((aligned(16))) float As[2][BM * PK];   // double-buffered: one barrier per k-tile
   __shared__ __attribute__((aligned(16))) float Bs[2][BN * PK];
 
@@ -171,8 +176,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   // tile t lives in register slot t % D until it is written to LDS buffer t & 1 during step t-1
   auto fetch = [&](int t, float (&fa)[RA], float (&fb)[RB]) {
     const int tc = t < nsteps ? t : nsteps - 1;   // past the end: harmless re-load, never written to LDS
-    load_tile<BM, A_KC, V4>(A, g.lda, m0, g.M, kbeg + tc * BK, kend, fa, tid);
-    load_tile<BN, B_KC, V4>(B, g.ldb, n0, g.N, kbeg + tc * BK, kend, fb, tid);
+    load_tile<BM, A_KC, V4, BK>(A, g.lda, m0, g.M, kbeg + tc * BK, kend, fa, tid);
+    load_tile<BN, B_KC, V4, BK>(B, g.ldb, n0, g.N, kbeg + tc * BK, kend, fb, tid);
   };
   // fused bias gradient of a wgrad GEMM: the workgroups of the first column tile also sum their A rows over k
   bool do_rs = false;
@@ -181,9 +186,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   if (nsteps > 0) {
     fetch(0, ra[0], rb[0]);
     if constexpr (!A_KC)
-      if (do_rs) rs += tile_rowsum<BM>(ra[0], m0, g.M, kbeg, kend, tid);
-    store_tile<BM, A_KC, V4>(As[0], ra[0], m0, g.M, kbeg, kend, tid);
-    store_tile<BN, B_KC, V4>(Bs[0], rb[0], n0, g.N, kbeg, kend, tid);
+      if (do_rs) rs += tile_rowsum<BM, BK>(ra[0], m0, g.M, kbeg, kend, tid);
+    store_tile<BM, A_KC, V4, BK>(As[0], ra[0], m0, g.M, kbeg, kend, tid);
+    store_tile<BN, B_KC, V4, BK>(Bs[0], rb[0], n0, g.N, kbeg, kend, tid);
 #pragma unroll
     for (int d = 1; d <= D; ++d) fetch(d, ra[d % D], rb[d % D]);
   }
@@ -213,9 +218,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
     if constexpr (!A_KC)
-      if (do_rs) rs += tile_rowsum<BM>(ra[(s + 1) % D], m0, g.M, kbeg + (t + 1) * BK, kend, tid);
-    store_tile<BM, A_KC, V4>(As[(s + 1) & 1], ra[(s + 1) % D], m0, g.M, kbeg + (t + 1) * BK, kend, tid);
-    store_tile<BN, B_KC, V4>(Bs[(s + 1) & 1], rb[(s + 1) % D], n0, g.N, kbeg + (t + 1) * BK, kend, tid);
+      if (do_rs) rs += tile_rowsum<BM, BK>(ra[(s + 1) % D], m0, g.M, kbeg + (t + 1) * BK, kend, tid);
+    store_tile<BM, A_KC, V4, BK>(As[(s + 1) & 1], ra[(s + 1) % D], m0, g.M, kbeg + (t + 1) * BK, kend, tid);
+    store_tile<BN, B_KC, V4, BK>(Bs[(s + 1) & 1], rb[(s + 1) % D], n0, g.N, kbeg + (t + 1) * BK, kend, tid);
     fetch(t + 1 + D, ra[(s + 1) % D], rb[(s + 1) % D]);
     __syncthreads();
   };
@@ -340,11 +345,11 @@ __global__ void splitk_reduce_kernel(GemmArgs g) {
   epilogue_store(g, batch, m, n, (s0 + s1) + (s2 + s3));
 }
 
-template <int TM, int TN, bool A_KC, bool B_KC, bool V4>
+template <int TM, int TN, bool A_KC, bool B_KC, bool V4, int BK = BK0>
 int launch(const GemmArgs& g, hipStream_t st) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.nbatch * g.splitk);
-  hipLaunchKernelGGL((gemm_kernel<TM, TN, A_KC, B_KC, V4>), grid, dim3(256), 0, st, g);
+  hipLaunchKernelGGL((gemm_kernel<TM, TN, A_KC, B_KC, V4, BK>), grid, dim3(256), 0, st, g);
   DRQ_LAUNCH_CHECK();
   if (g.splitk > 1) {
     const long mn = (long)g.M * g.N;
@@ -355,15 +360,26 @@ int launch(const GemmArgs& g, hipStream_t st) {
   return DRQ_OK;
 }
 
-template <int TM, int TN>
+template <int TM, int TN, int BK = BK0>
 int dispatch(const GemmArgs& g, int a_kc, int b_kc, bool v4, hipStream_t st) {
-  if (a_kc && b_kc) return v4 ? launch<TM, TN, true, true, true>(g, st) : launch<TM, TN, true, true, false>(g, st);
-  if (a_kc && !b_kc) return v4 ? launch<TM, TN, true, false, true>(g, st) : launch<TM, TN, true, false, false>(g, st);
-  if (!a_kc && !b_kc) return launch<TM, TN, false, false, false>(g, st);
+  if (a_kc && b_kc)
+    return v4 ? launch<TM, TN, true, true, true, BK>(g, st) : launch<TM, TN, true, true, false, BK>(g, st);
+  if (a_kc && !b_kc)
+    return v4 ? launch<TM, TN, true, false, true, BK>(g, st) : launch<TM, TN, true, false, false, BK>(g, st);
+  if (!a_kc && !b_kc) return launch<TM, TN, false, false, false, BK>(g, st);
   return DRQ_EARG;
 }
 
 }  // namespace
+
+// skinny.hip
+int drq_skinny_dgrad(const float* dz, long lda, const float* w, long ldb, float* c, long ldc, int M, int N, int K,
+                     const float* aux, int ldaux, int scatter_hw, hipStream_t st);
+
+// gemm2.hip
+int drq_gemm2(int nbatch, const float* const* A, long lda, int a_kc, const float* const* B, long ldb, int b_kc,
+              float* const* C, long ldc, int M, int N, int K, const float* const* bias, int relu,
+              const float* const* aux, int ldaux, float* const* rowsum, hipStream_t st);
 
 extern "C" {
 
@@ -376,11 +392,24 @@ int drq_gemm_batched_f32(int nbatch, const float* const* A, long lda, int a_kc, 
   for (int b = 0; b < nbatch; ++b)
     if (!A[b] || !B[b] || !C[b]) return DRQ_EARG;
   if (rowsum && a_kc) return DRQ_EARG;
+  // the skinny dgrad shape of the trunk layer (K = feature_dim, N = 39200) has its own kernel; an explicit
+  // tile / splitk request keeps the generic path (tests compare the two)
+  if (nbatch == 1 && tile == 0 && splitk == 0 && N >= 4096 && N % 32 == 0 && !bias && !relu && a_kc && !b_kc &&
+      K <= 128 && !rowsum) {
+    const int rc =
+        drq_skinny_dgrad(A[0], lda, B[0], ldb, C[0], ldc, M, N, K, aux ? aux[0] : nullptr, ldaux, scatter_hw, st);
+    if (rc != DRQ_EARG) return rc;
+  }
+  // hidden x hidden layers at multiple-of-32 shapes: the LDS-free kernel (gemm2.hip)
+  if (tile == 0 && splitk == 0 && scatter_hw == 0) {
+    const int rc = drq_gemm2(nbatch, A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, bias, relu, aux, ldaux, rowsum, st);
+    if (rc != DRQ_EARG) return rc;
+  }
   const int cus = drq_num_cus();
   const long t_big = (long)((M + 63) / 64) * ((N + 63) / 64) * nbatch;
   const long t_small = (long)((M + 31) / 32) * ((N + 31) / 32) * nbatch;
   if (tile == 0) tile = (t_big >= 2L * cus) ? 2 : 1;
-  const long tiles = tile == 2 ? t_big : t_small;
+  const long tiles = tile == 2 ? t_big : (tile >= 3 ? (t_big + t_small) / 2 : t_small);
   if (rowsum) splitk = 1;
   if (splitk == 0) {
     splitk = 1;
@@ -391,7 +420,7 @@ int drq_gemm_batched_f32(int nbatch, const float* const* A, long lda, int a_kc, 
       if (splitk < 1) splitk = 1;
     }
   }
-  int kchunk = ((K + splitk - 1) / splitk + BK - 1) / BK * BK;
+  int kchunk = ((K + splitk - 1) / splitk + 63) / 64 * 64;
   splitk = (K + kchunk - 1) / kchunk;
   if (splitk > 1 && (!ws || (size_t)nbatch * splitk * M * N * sizeof(float) > ws_bytes)) return DRQ_EWS;
   GemmArgs g{};
@@ -410,6 +439,10 @@ int drq_gemm_batched_f32(int nbatch, const float* const* A, long lda, int a_kc, 
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
   g.nbatch = nbatch; g.splitk = splitk; g.kchunk = kchunk; g.part = ws;
   g.ep.ldaux = ldaux; g.ep.relu = relu; g.ep.scatter_hw = scatter_hw;
+  if (tile == 3) return dispatch<2, 1>(g, a_kc, b_kc, v4, st);   // 64x32 block tile
+  if (tile == 4) return dispatch<1, 2>(g, a_kc, b_kc, v4, st);   // 32x64
+  if (tile == 5) return dispatch<1, 1, 64>(g, a_kc, b_kc, v4, st);   // 32x32, k-tile 64 (one barrier per 64 k)
+  if (tile == 6) return dispatch<2, 2, 64>(g, a_kc, b_kc, v4, st);   // 64x64, k-tile 64
   return tile == 2 ? dispatch<2, 2>(g, a_kc, b_kc, v4, st) : dispatch<1, 1>(g, a_kc, b_kc, v4, st);
 }
 

@@ -1,0 +1,138 @@
+// Skinny f32 GEMM of the trunk layer Linear(39200 -> feature_dim) (drqv2.py:74) in backward:
+//
+//   dgrad  dX[m][n] = (mask[m][n] > 0) * sum_k dz[m][k] W[k][n]        M = batch, N = 39200, K = feature_dim
+//
+// The reduction is 50/100 long and the kernel is bound by the 40 MB mask it reads and the 40 MB gradient it
+// writes; the generic tiled GEMM (gemm.hip) spends its time in a 64-byte-segment epilogue.  Here a wave owns 32
+// consecutive columns n and keeps W[:, n] for the whole reduction in registers as the B operand of
+// v_mfma_f32_32x32x2_f32 (lane = column, lane>>5 = k parity; loaded once, 128-byte row segments), dz is staged
+// transposed in LDS and is the A operand, and the C/D layout of the 32x32 MFMA puts 32 consecutive n in the
+// lanes, so stores and mask loads are 128-byte segments.  Deterministic (fixed k order, no atomics).
+// (The matching wgrad shape, dW = dz^T X, was tried the same way and only tied the generic kernel: 27 us,
+// bound by two half-filled rounds of workgroups rather than by memory; it stays on gemm.hip.)
+#include "common.h"
+
+namespace {
+
+constexpr unsigned kDropOff = 0x80000000u;   // buffer offset beyond any num_records: load returns 0, store is dropped
+
+__device__ __forceinline__ int rowmap(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+struct SkinnyD {
+  const float* dz;    // [M][lda]
+  const float* w;     // [K][ldb]
+  const float* aux;   // [M][ldaux] or null
+  float* c;
+  long lda, ldb, ldc;
+  int ldaux;
+  int M, N, K;
+  int scatter_hw;     // >0: padded (pad 2) NCHW scatter of column n = (ch, y, x), see gemm.hip
+  unsigned c_bytes, aux_bytes;
+  int mt_per_block;   // 32-row tiles of M per workgroup
+};
+
+// KP = k pairs kept in registers (K <= 2*KP)
+template <int KP>
+__global__ __launch_bounds__(256, (KP <= 32 ? 5 : 2)) void skinny_dgrad_kernel(SkinnyD g) {
+  extern __shared__ float lds[];   // dz^T: [2*KP][MP]
+  const int MB = g.mt_per_block * 32;
+  const int MP = MB + 33;          // pitch = 33 mod 64 when MB % 64 == 0: conflict-free transposing writes
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  const int mbase = blockIdx.y * MB;
+
+  // stage dz rows [mbase, mbase+MB) transposed, zero outside the matrix
+  for (int idx = tid; idx < MB * 2 * KP; idx += 256) {
+    const int m = idx / (2 * KP), k = idx - m * (2 * KP);
+    const bool ok = (mbase + m < g.M) && (k < g.K);
+    lds[k * MP + m] = ok ? g.dz[(long)(mbase + m) * g.lda + k] : 0.f;
+  }
+
+  const int n = (blockIdx.x * 4 + wid) * 32 + col;
+  const bool nok = n < g.N;
+  const int nc = nok ? n : g.N - 1;
+  float wv[KP];
+#pragma unroll
+  for (int kp = 0; kp < KP; ++kp) {
+    const int k = 2 * kp + half;
+    const float v = g.w[(long)(k < g.K ? k : g.K - 1) * g.ldb + nc];
+    wv[kp] = (k < g.K && nok) ? v : 0.f;
+  }
+  __syncthreads();
+
+  // output / mask addressing: the column part is fixed for the wave
+  long cn = nc;
+  long crow = g.ldc;
+  if (g.scatter_hw > 0) {
+    const int hw = g.scatter_hw, hp = hw + 4;
+    const int ch = nc / (hw * hw);
+    const int rr = nc - ch * hw * hw;
+    const int y = rr / hw, x = rr - y * hw;
+    cn = ((long)ch * hp + (y + 2)) * hp + (x + 2);
+    crow = 32L * hp * hp;
+  }
+  const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void*)g.c, 0, g.c_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ars =
+      __builtin_amdgcn_make_buffer_rsrc((void*)g.aux, 0, g.aux ? g.aux_bytes : 0, 0x00020000);
+  const bool use_mask = g.aux != nullptr;
+
+  const float* a0 = lds + half * MP + col;
+  const int ntile = min(g.mt_per_block, (g.M - mbase + 31) / 32);
+  // mask loads one tile ahead (zero-sized descriptor without a mask: returns 0, unused)
+  auto load_mask = [&](float (&mv)[16], int mt) {
+    const int m0 = mbase + mt * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + rowmap(r, half);
+      const unsigned off = (m < g.M && nok) ? (unsigned)(((long)m * g.ldaux + n) * 4) : kDropOff;
+      mv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ars, off, 0, 0));
+    }
+  };
+  float mv[16], mn[16];
+  load_mask(mv, 0);
+  for (int mt = 0; mt < ntile; ++mt) {
+    const int m0 = mbase + mt * 32;
+    load_mask(mn, mt + 1 < ntile ? mt + 1 : mt);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* ap = a0 + mt * 32;
+#pragma unroll
+    for (int kp = 0; kp < KP; ++kp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * kp * MP], wv[kp], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + rowmap(r, half);
+      float v = acc[r];
+      if (use_mask) v = mv[r] > 0.f ? v : 0.f;
+      const unsigned off = (m < g.M && nok) ? (unsigned)(((long)m * crow + cn) * 4) : kDropOff;
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), crs, off, 0, 0);
+      mv[r] = mn[r];
+    }
+  }
+}
+
+}  // namespace
+
+// ---- launchers used by drq_gemm_batched_f32 (gemm.hip); return DRQ_EARG when the shape is not theirs -------------
+int drq_skinny_dgrad(const float* dz, long lda, const float* w, long ldb, float* c, long ldc, int M, int N, int K,
+                     const float* aux, int ldaux, int scatter_hw, hipStream_t st) {
+  if (K > 128 || N % 32 != 0) return DRQ_EARG;
+  const long crow = scatter_hw > 0 ? 32L * (scatter_hw + 4) * (scatter_hw + 4) : ldc;
+  const size_t cb = (size_t)M * crow * 4, ab = aux ? (size_t)M * ldaux * 4 : 0;
+  if (cb >= (1ull << 31) || ab >= (1ull << 31)) return DRQ_EARG;
+  SkinnyD g{dz, w, aux, c, lda, ldb, ldc, ldaux, M, N, K, scatter_hw, (unsigned)cb, (unsigned)ab, 0};
+  const int mtiles = (M + 31) / 32;
+  g.mt_per_block = mtiles >= 4 ? 2 : mtiles;     // 4 workgroups along M at B = 256: ~5 waves per SIMD
+  if (K > 64 && g.mt_per_block > 2) g.mt_per_block = 2;   // dynamic LDS stays under 64 KB
+  const int MB = g.mt_per_block * 32;
+  dim3 grid((N / 32 + 3) / 4, (mtiles + g.mt_per_block - 1) / g.mt_per_block);
+  // the two feature dimensions of the reference's configs (50, 100) get exact register tiles
+  const int kp = K == 50 ? 25 : K <= 64 ? 32 : K == 100 ? 50 : 64;
+  const size_t lds = (size_t)2 * kp * (MB + 33) * 4;
+  if (kp == 25) hipLaunchKernelGGL(skinny_dgrad_kernel<25>, grid, dim3(256), lds, st, g);
+  else if (kp == 32) hipLaunchKernelGGL(skinny_dgrad_kernel<32>, grid, dim3(256), lds, st, g);
+  else if (kp == 50) hipLaunchKernelGGL(skinny_dgrad_kernel<50>, grid, dim3(256), lds, st, g);
+  else hipLaunchKernelGGL(skinny_dgrad_kernel<64>, grid, dim3(256), lds, st, g);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}

@@ -333,7 +333,7 @@ int phase_critic_heads(const Ctx& c) {
     float *gw[1] = {c.g(cr.trunk_w)}, *gb[1] = {c.g(cr.trunk_b)}, *dy4[1] = {c.ws(W_DY4)};
     CK(c.wgrad(1, dz, F, x, R, gw, gb, B, F, (int)R));
     // d feat = dz W_t, masked by relu(conv4) and scattered into the padded conv-gradient layout
-    CK(drq_gemm_batched_f32(1, dz, F, 1, w, R, 0, dy4, 0, B, (int)R, F, nullptr, 0, mk, (int)R, nullptr, 35, 0, 1,
+    CK(drq_gemm_batched_f32(1, dz, F, 1, w, R, 0, dy4, 0, B, (int)R, F, nullptr, 0, mk, (int)R, nullptr, 35, 0, 0,
                             c.gemm_ws(), c.gemm_ws_bytes(), st));
   }
 

@@ -194,18 +194,20 @@ def _ptr_array(ts):
 
 
 def gemm_batched(As, a_kc, Bs, b_kc, M, N, K, lda, ldb, biases=None, relu=False, auxs=None, rowsum=False, tile=0,
-                 splitk=0):
-    """n independent problems of one shape in a single launch.  Returns (list of C, list of rowsum or None)."""
+                 splitk=0, scatter_hw=0, Cs=None):
+    """n independent problems of one shape in a single launch.  Returns (list of C, list of rowsum or None).
+    scatter_hw > 0: C_i is a caller-provided zero-padded [M][32][hw+4][hw+4] gradient buffer (pass Cs)."""
     lib = _lib.load()
     n = len(As)
     dev = As[0].device
-    Cs = [torch.empty((M, N), device=dev, dtype=torch.float32) for _ in range(n)]
+    if Cs is None:
+        Cs = [torch.empty((M, N), device=dev, dtype=torch.float32) for _ in range(n)]
     rs = [torch.empty((M,), device=dev, dtype=torch.float32) for _ in range(n)] if rowsum else None
     ws = torch.empty((16 * 1024 * 1024,), device=dev, dtype=torch.float32)
     check(lib.drq_gemm_batched_f32(n, _ptr_array(As), lda, int(a_kc), _ptr_array(Bs), ldb, int(b_kc), _ptr_array(Cs),
                                    N, M, N, K, _ptr_array(biases) if biases else None, int(relu),
                                    _ptr_array(auxs) if auxs else None, (auxs[0].shape[-1] if auxs else 0),
-                                   _ptr_array(rs) if rs else None, 0, tile, splitk, ptr(ws), ws.numel() * 4,
+                                   _ptr_array(rs) if rs else None, scatter_hw, tile, splitk, ptr(ws), ws.numel() * 4,
                                    _stream()), "drq_gemm_batched_f32")
     return Cs, rs
 

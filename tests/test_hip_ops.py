@@ -205,7 +205,7 @@ def test_unsupported_shapes_are_refused(ops):
 
 
 @pytest.mark.parametrize("Brows,N,K,n", [(256, 1024, 1024, 2), (9, 50, 39200, 1), (31, 1024, 56, 2), (12, 6, 1024, 1),
-                                         (40, 70, 33, 3)])
+                                         (40, 70, 33, 3), (256, 50, 39200, 1), (300, 100, 8192, 1), (5, 21, 4096, 1)])
 def test_gemm_batched_wgrad_with_fused_bias_grad(ops, Brows, N, K, n):
     """dW_i = dy_i^T x_i and db_i = column sums of dy_i from ONE launch, independent pointers per problem"""
     dys = [rnd(Brows, N, seed=10 + i) for i in range(n)]
@@ -215,6 +215,31 @@ def test_gemm_batched_wgrad_with_fused_bias_grad(ops, Brows, N, K, n):
     for dy, x, c, r in zip(dys, xs, Cs, rs):
         assert nerr(c, dy.double().t() @ x.double()) <= 3e-6
         assert nerr(r, dy.double().sum(0)) <= 3e-6
+
+
+@pytest.mark.parametrize("M,K,hw", [(256, 50, 35), (8, 50, 35), (70, 100, 12), (33, 21, 16)])
+def test_skinny_trunk_dgrad_matches_generic_path_and_fp64(ops, M, K, hw):
+    """dX = (dz W) * (mask > 0) for the trunk shape (short K, N = 32*hw*hw): the dedicated kernel (automatic
+    dispatch) against the generic tiled GEMM (explicit tile) and fp64, dense and padded-scatter output."""
+    N = 32 * hw * hw
+    dz, w = rnd(M, K, seed=1), rnd(K, N, seed=2, scale=K ** -0.5)
+    mask = rnd(M, N, seed=3)
+    ref = (dz.double() @ w.double()) * (mask.double() > 0)
+    args = ([dz.cuda()], True, [w.cuda()], False, M, N, K, K, N)
+    (c_fast,), _ = ops.gemm_batched(*args, auxs=[mask.cuda()])
+    (c_gen,), _ = ops.gemm_batched(*args, auxs=[mask.cuda()], tile=2, splitk=1)
+    assert nerr(c_fast, ref) <= 3e-6 and nerr(c_gen, ref) <= 3e-6
+    (c_nomask,), _ = ops.gemm_batched(*args)
+    assert nerr(c_nomask, dz.double() @ w.double()) <= 3e-6
+    hp = hw + 4
+    pads = [torch.zeros(M, 32, hp, hp, device="cuda") for _ in range(2)]
+    ops.gemm_batched(*args, auxs=[mask.cuda()], scatter_hw=hw, Cs=[pads[0]])
+    ops.gemm_batched(*args, auxs=[mask.cuda()], scatter_hw=hw, Cs=[pads[1]], tile=2, splitk=1)
+    assert torch.equal(pads[0][:, :, 2:-2, 2:-2].reshape(M, N), c_fast)          # same values, scattered
+    assert nerr(pads[1][:, :, 2:-2, 2:-2].reshape(M, N), ref) <= 3e-6
+    border = pads[0].clone()
+    border[:, :, 2:-2, 2:-2] = 0
+    assert float(border.abs().sum()) == 0.0                                     # the zero border is never written
 
 
 def test_gemm_batched_forward_four_problems(ops):

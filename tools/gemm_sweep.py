@@ -37,22 +37,25 @@ def timeit(fn, reps=10):
 
 cases = {
     # name: (A, lda, a_kc, B, ldb, b_kc, M, N, K, nbatch, a_bs, b_bs)
+    "mlp_fwd_x4   M256 N1024 K1024": (rn(4, B, H), H, 1, rn(4, H, H), H, 1, B, H, H, 4, B * H, H * H),
     "mlp_fwd_x2   M256 N1024 K1024": (rn(2, B, H), H, 1, rn(2, H, H), H, 1, B, H, H, 2, B * H, H * H),
+    "pol_fwd_x1   M512 N1024 K1024": (rn(2 * B, H), H, 1, rn(H, H), H, 1, 2 * B, H, H, 1, 0, 0),
+    "pol_wgrad_x1 M1024 N1024 K256": (rn(B, H), H, 0, rn(B, H), H, 0, H, H, B, 1, 0, 0),
+    "pol_dgrad_x1 M256 N1024 K1024": (rn(B, H), H, 1, rn(H, H), H, 0, B, H, H, 1, 0, 0),
     "mlp_fwd_x1   M256 N1024 K1024": (rn(B, H), H, 1, rn(H, H), H, 1, B, H, H, 1, 0, 0),
     "mlp_dgrad_x2 M256 N1024 K1024": (rn(2, B, H), H, 1, rn(2, H, H), H, 0, B, H, H, 2, B * H, H * H),
     "mlp_wgrad_x2 M1024 N1024 K256": (rn(2, B, H), H, 0, rn(2, B, H), H, 0, H, H, B, 2, B * H, B * H),
-    "trunk_fwd_x2 M256 N50 K39200": (rn(B, R), R, 1, rn(2, 50, R), R, 1, B, 50, R, 2, 0, 50 * R),
+
     "trunk_fwd_x1 M256 N50 K39200": (rn(B, R), R, 1, rn(50, R), R, 1, B, 50, R, 1, 0, 0),
     "trunk_wgrad  M50 N39200 K256": (rn(B, 50), 50, 0, rn(B, R), R, 0, 50, R, B, 1, 0, 0),
-    "trunk_dgrad  M256 N39200 K50": (rn(B, 50), 50, 1, rn(50, R), R, 0, B, R, 50, 1, 0, 0),
-    "q1_fwd_x2    M256 N1024 K56": (rn(B, 56), 56, 1, rn(2, H, 56), 56, 1, B, H, 56, 2, 0, H * 56),
-    "q3_fwd_x2    M256 N1 K1024": (rn(2, B, H), H, 1, rn(2, 1, H), H, 1, B, 1, H, 2, B * H, H),
-    "q3_dgrad_x2  M256 N1024 K1": (rn(2, B, 1), 1, 1, rn(2, 1, H), H, 0, B, H, 1, 2, B, H),
+    "q1_fwd_x4    M256 N1024 K56": (rn(B, 56), 56, 1, rn(4, H, 56), 56, 1, B, H, 56, 4, 0, H * 56),
+    "q1_wgrad_x2  M1024 N56 K256": (rn(2, B, H), H, 0, rn(B, 56), 56, 0, H, 56, B, 2, B * H, 0),
+    "q1_dgrad_x2  M256 N56 K1024": (rn(2, B, H), H, 1, rn(2, H, 56), 56, 0, B, 56, H, 2, B * H, H * 56),
 }
 for name, (A, lda, akc, Bm, ldb, bkc, M, N, K, nb, abs_, bbs) in cases.items():
     C = torch.empty(nb, M, N, device=dev)
     out = []
-    for tile in (1, 2):
+    for tile in (1, 2, 5, 6):
         for sk in (1, 2, 4, 8, 16, 24, 48, 96):
             if sk > 1 and K // sk < 64:
                 continue
