@@ -837,6 +837,49 @@ __global__ __launch_bounds__(1024) void conv3x3_wgrad_reduce_kernel(const float*
   }
 }
 
+// the same reduction for up to 4 layers in one launch (blockIdx.y = layer): the encoder backward defers the four
+// per-layer reductions to its end (nothing reads dW/db before the optimiser step)
+struct ReduceJob {
+  const float* part;
+  float* dw;
+  float* db;
+  int nblocks, cin, small;
+};
+struct ReduceJobs {
+  ReduceJob j[4];
+};
+
+__global__ __launch_bounds__(1024) void conv3x3_wgrad_reduce_multi_kernel(ReduceJobs js) {
+  const ReduceJob J = js.j[blockIdx.y];
+  const int NT = J.small ? 3 : 9;
+  const int PART = NT * 1024 + 64;
+  __shared__ float sm[16][64];
+  const int e = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + e;
+  if (blockIdx.x * 64 >= PART) return;      // uniform per workgroup
+  float s = 0.f;
+  for (int k = grp; k < J.nblocks; k += 16) s += J.part[(long)k * PART + i];
+  sm[grp][e] = s;
+  __syncthreads();
+  if (grp != 0) return;
+  float tot = 0.f;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) tot += sm[g][e];
+  if (i < NT * 1024) {
+    const int t = i >> 10, r = (i >> 6) & 15, lane = i & 63;
+    const int col = lane & 31, half = lane >> 5;
+    const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (J.small) {
+      if (col < J.cin * 3) J.dw[(co * J.cin + col / 3) * 9 + t * 3 + col % 3] = tot;
+    } else {
+      if (col < J.cin) J.dw[(co * J.cin + col) * 9 + t] = tot;
+    }
+  } else {
+    const float other = __shfl_xor(tot, 32);
+    if (e < 32) J.db[e] = tot + other;
+  }
+}
+
 template <int CIN, int HIN, int STRIDE, int BLK, int TPW, int ABL = 0, bool MASK = false>
 int launch_conv_v(const ConvArgs& a, hipStream_t st) {
   constexpr int HOUT = (HIN - 3) / STRIDE + 1;
@@ -902,8 +945,11 @@ inline int wgrad_variant() {     // DRQ_WGRAD_VARIANT (development knob, read on
   return v;
 }
 
+// defer: run only the partial-sum kernel (records in ws, their count in *nblocks_out); the caller reduces several
+// layers with one launch of conv3x3_wgrad_reduce_multi_kernel
 template <int CIN, int HIN, int STRIDE>
-int launch_wgrad(const WgradArgs& a0, float* dw, float* db, float* ws, size_t ws_bytes, hipStream_t st) {
+int launch_wgrad(const WgradArgs& a0, float* dw, float* db, float* ws, size_t ws_bytes, hipStream_t st,
+                 bool defer = false, int* nblocks_out = nullptr) {
   using G = WgradGeom<CIN, HIN, STRIDE>;
   using G2 = Wgrad2Geom<CIN, HIN, STRIDE>;
   static_assert(4 * G::WAVE_LDS * 4 <= 160 * 1024, "LDS tile too large");
@@ -944,6 +990,8 @@ int launch_wgrad(const WgradArgs& a0, float* dw, float* db, float* ws, size_t ws
       }
       hipLaunchKernelGGL((conv3x3_wgrad3_kernel<HIN>), dim3((unsigned)blocks), dim3(256), lds3 * 4, st, a);
       DRQ_LAUNCH_CHECK();
+      if (nblocks_out) *nblocks_out = (int)blocks;
+      if (defer) return DRQ_OK;
       hipLaunchKernelGGL((conv3x3_wgrad_reduce_kernel<CIN, G::SMALL>), dim3(G::PART / 64), dim3(1024), 0, st,
                          (const float*)ws, (int)blocks, dw, db);
       DRQ_LAUNCH_CHECK();
@@ -957,6 +1005,8 @@ int launch_wgrad(const WgradArgs& a0, float* dw, float* db, float* ws, size_t ws
     hipLaunchKernelGGL((conv3x3_wgrad_kernel<CIN, HIN, STRIDE>), dim3((unsigned)blocks), dim3(256), lds_floats * 4,
                        st, a);
   DRQ_LAUNCH_CHECK();
+  if (nblocks_out) *nblocks_out = (int)blocks;
+  if (defer) return DRQ_OK;
   hipLaunchKernelGGL((conv3x3_wgrad_reduce_kernel<CIN, G::SMALL>), dim3(G::PART / 64), dim3(1024), 0, st,
                      (const float*)ws, (int)blocks, dw, db);
   DRQ_LAUNCH_CHECK();
@@ -964,6 +1014,42 @@ int launch_wgrad(const WgradArgs& a0, float* dw, float* db, float* ws, size_t ws
 }
 
 }  // namespace
+
+// ---- internal entry points of the step orchestration (step.hip): per-layer partial sums now, one reduction later
+int drq_conv3x3_wgrad_partial(const float* x, const float* dy, int nb, int cin, int hin, int stride, long dy_bs,
+                              long dy_cs, long dy_rs, long dy_off, float* part, size_t part_bytes, int* nblocks,
+                              hipStream_t st) {
+  if (!x || !dy || !part || !nblocks || nb <= 0) return DRQ_EARG;
+  const size_t xb = (size_t)nb * cin * hin * hin * 4;
+  const size_t dyb = (size_t)nb * dy_bs * 4;
+  if (xb >= (1ull << 31) || dyb >= (1ull << 31) || dy_off < 0 || dy_bs <= 0) return DRQ_EARG;
+  WgradArgs a{x, dy, dy_bs, dy_cs, dy_rs, dy_off, nullptr, (unsigned)xb, (unsigned)dyb, nb};
+  if (cin == 9 && hin == 84 && stride == 2)
+    return launch_wgrad<9, 84, 2>(a, nullptr, nullptr, part, part_bytes, st, true, nblocks);
+  if (cin == 32 && stride == 1) {
+    if (hin == 41) return launch_wgrad<32, 41, 1>(a, nullptr, nullptr, part, part_bytes, st, true, nblocks);
+    if (hin == 39) return launch_wgrad<32, 39, 1>(a, nullptr, nullptr, part, part_bytes, st, true, nblocks);
+    if (hin == 37) return launch_wgrad<32, 37, 1>(a, nullptr, nullptr, part, part_bytes, st, true, nblocks);
+  }
+  return DRQ_EARG;
+}
+
+int drq_conv3x3_wgrad_reduce_multi(int n, const float* const* part, const int* nblocks, const int* cin,
+                                   float* const* dw, float* const* db, hipStream_t st) {
+  if (n <= 0 || n > 4 || !part || !nblocks || !cin || !dw || !db) return DRQ_EARG;
+  ReduceJobs js{};
+  int maxpart = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!part[i] || !dw[i] || !db[i] || nblocks[i] <= 0) return DRQ_EARG;
+    const int small = cin[i] * 3 <= 32;
+    js.j[i] = ReduceJob{part[i], dw[i], db[i], nblocks[i], cin[i], small};
+    const int p = (small ? 3 : 9) * 1024 + 64;
+    if (p > maxpart) maxpart = p;
+  }
+  hipLaunchKernelGGL(conv3x3_wgrad_reduce_multi_kernel, dim3(maxpart / 64, n), dim3(1024), 0, st, js);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
 
 // ------------------------------------------------------------------------------------------------
 // C ABI (declared in include/drqv2_hip.h)

@@ -85,6 +85,9 @@ struct LnArgs {
   float* rstd[4];         // [rows]   (may be null)
   int ldz[4], ldo[4];
   int rows, F;
+  const float* tail[4];   // optional [rows][tail_ld]: copied into out columns [F, F+tail_n) (the [h, action] concat)
+  int tail_ld[4];
+  int tail_n;
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -128,6 +131,7 @@ __global__ void ln_tanh_fwd_kernel(LnArgs a) {
     }
   }
   if (lane == 0 && a.rstd[g]) a.rstd[g][row] = rstd;
+  if (a.tail[g] && lane < a.tail_n) a.out[g][(long)row * a.ldo[g] + a.F + lane] = a.tail[g][(long)row * a.tail_ld[g] + lane];
 }
 
 struct LnBwdArgs {
@@ -314,7 +318,8 @@ __global__ void td_loss_kernel(const float* tq1, const float* tq2, const float* 
 // sums[5] = sum -min(q1,q2), sums[6] = sum_b sum_A log N(a|mu,std)
 // ------------------------------------------------------------------------------------------------
 __global__ void actor_loss_kernel(const float* q1, const float* q2, const float* a, long lda, const float* mu,
-                                  float std, float* dq1, float* dq2, float* sums, int B, int A, float invB) {
+                                  float std, float* dq1, float* dq2, float* sums, int B, int A, float invB,
+                                  float* sums_host, unsigned seq) {
   __shared__ float sm[4][256];
   float s[4] = {0.f, 0.f, 0.f, 0.f};
   const float log_std = logf(std);
@@ -337,6 +342,12 @@ __global__ void actor_loss_kernel(const float* q1, const float* q2, const float*
   if (threadIdx.x == 0) {
     sums[5] = s[0];
     sums[6] = s[1];
+    if (sums_host) {   // metrics mirror (DrqStep.sums_host): all eight sums, then the sequence word
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sums_host[i] = i == 5 ? s[0] : (i == 6 ? s[1] : sums[i]);
+      __threadfence_system();
+      __hip_atomic_store((unsigned*)(sums_host + 8), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -374,6 +385,39 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     v[i] = vi;
     p[i] = pi;
     if (tgt) tgt[i] = __fadd_rn(__fmul_rn(tau, pi), __fmul_rn(one_minus_tau, tgt[i]));
+  }
+}
+
+struct AdamSeg2 {
+  float* p[2];
+  const float* g[2];
+  float* m[2];
+  float* v[2];
+  long n[2];
+  float neg_step_size[2], sqrt_bc2[2];
+  float gscale;
+};
+
+__global__ void adam2_kernel(AdamSeg2 a) {
+#pragma clang fp contract(off)
+  const int z = blockIdx.y;
+  float* __restrict__ p = a.p[z];
+  const float* __restrict__ g = a.g[z];
+  float* __restrict__ m = a.m[z];
+  float* __restrict__ v = a.v[z];
+  const long n = a.n[z];
+  const float neg_step_size = a.neg_step_size[z], sqrt_bc2 = a.sqrt_bc2[z];
+  const float w1 = (float)(1.0 - 0.9), b2 = 0.999f, w2 = (float)(1.0 - 0.999), eps = 1e-8f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float gi = g[i];
+    if (a.gscale != 1.0f) gi *= a.gscale;
+    const float mi = __fmaf_rn(w1, __fsub_rn(gi, m[i]), m[i]);
+    const float vi = __fmaf_rn(__fmul_rn(gi, w2), gi, __fmul_rn(v[i], b2));
+    const float denom = __fadd_rn(__fdiv_rn(sqrtf(vi), sqrt_bc2), eps);
+    const float pi = __fadd_rn(p[i], __fdiv_rn(__fmul_rn(neg_step_size, mi), denom));
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = pi;
   }
 }
 
@@ -489,6 +533,14 @@ inline unsigned grid_for(long n, int block = 256) {
 
 extern "C" {
 
+int drq_ln_tanh_fwd_multi_ex(int n, const float* const* z, int ldz, const float* const* gamma,
+                             const float* const* beta, float* const* out, const int* ldo, float* const* xhat,
+                             float* const* rstd, int rows, int F, const float* const* tail, const int* tail_ld,
+                             int tail_n, hipStream_t st);
+int drq_actor_loss_ex(const float* q1, const float* q2, const float* a, long lda, const float* mu, float std,
+                      float* dq1, float* dq2, float* sums, int B, int A, float inv_global_B, float* sums_host,
+                      unsigned seq, hipStream_t st);
+
 int drq_aug_fwd(const uint8_t* obs, const float* shift_xy, const float* base_grid, float* out, int n, int c,
                 int hw, int pad, int fuse_norm, hipStream_t st) {
   if (!obs || !shift_xy || !base_grid || !out || n <= 0 || c <= 0 || hw <= 0 || pad < 0) return DRQ_EARG;
@@ -584,8 +636,22 @@ int drq_qout_bwd(int nz, const float* const* dq, const float* const* h, const fl
 int drq_ln_tanh_fwd_multi(int n, const float* const* z, int ldz, const float* const* gamma, const float* const* beta,
                           float* const* out, const int* ldo, float* const* xhat, float* const* rstd, int rows, int F,
                           hipStream_t st) {
+  return drq_ln_tanh_fwd_multi_ex(n, z, ldz, gamma, beta, out, ldo, xhat, rstd, rows, F, nullptr, nullptr, 0, st);
+}
+
+// internal form used by the step: problem i may also copy tail_n (<= 64) columns of tail[i] behind its F outputs
+int drq_ln_tanh_fwd_multi_ex(int n, const float* const* z, int ldz, const float* const* gamma,
+                             const float* const* beta, float* const* out, const int* ldo, float* const* xhat,
+                             float* const* rstd, int rows, int F, const float* const* tail, const int* tail_ld,
+                             int tail_n, hipStream_t st) {
   if (n <= 0 || n > 4 || !z || !gamma || !beta || !out || !ldo || rows <= 0 || F <= 0 || F > 256) return DRQ_EARG;
+  if (tail && (tail_n <= 0 || tail_n > 64 || !tail_ld)) return DRQ_EARG;
   LnArgs a{};
+  a.tail_n = tail ? tail_n : 0;
+  for (int i = 0; i < n && tail; ++i) {
+    a.tail[i] = tail[i];
+    a.tail_ld[i] = tail_ld[i];
+  }
   for (int i = 0; i < n; ++i) {
     if (!z[i] || !gamma[i] || !beta[i] || !out[i]) return DRQ_EARG;
     a.z[i] = z[i]; a.gamma[i] = gamma[i]; a.beta[i] = beta[i]; a.out[i] = out[i];
@@ -633,13 +699,20 @@ int drq_td_mse(const float* tq1, const float* tq2, const float* q1, const float*
   return DRQ_OK;
 }
 
-int drq_actor_loss(const float* q1, const float* q2, const float* a, long lda, const float* mu, float std,
-                   float* dq1, float* dq2, float* sums, int B, int A, float inv_global_B, hipStream_t st) {
+// internal form used by the step: also publishes the eight sums to the pinned host mirror (DrqStep.sums_host)
+int drq_actor_loss_ex(const float* q1, const float* q2, const float* a, long lda, const float* mu, float std,
+                      float* dq1, float* dq2, float* sums, int B, int A, float inv_global_B, float* sums_host,
+                      unsigned seq, hipStream_t st) {
   if (!q1 || !q2 || !a || !mu || !dq1 || !dq2 || !sums || B <= 0 || A <= 0) return DRQ_EARG;
   hipLaunchKernelGGL(actor_loss_kernel, dim3(1), dim3(256), 0, st, q1, q2, a, lda, mu, std, dq1, dq2, sums, B, A,
-                     inv_global_B);
+                     inv_global_B, sums_host, seq);
   DRQ_LAUNCH_CHECK();
   return DRQ_OK;
+}
+
+int drq_actor_loss(const float* q1, const float* q2, const float* a, long lda, const float* mu, float std,
+                   float* dq1, float* dq2, float* sums, int B, int A, float inv_global_B, hipStream_t st) {
+  return drq_actor_loss_ex(q1, q2, a, lda, mu, std, dq1, dq2, sums, B, A, inv_global_B, nullptr, 0u, st);
 }
 
 int drq_actor_dmu(const float* dha1, const float* dha2, long ld, int col0, const float* mu, float* dpre, int B,
@@ -653,6 +726,29 @@ int drq_actor_dmu(const float* dha1, const float* dha2, long ld, int col0, const
 
 // step = 1-based Adam step count; bias corrections are formed in double on the host exactly as
 // torch/optim/adam.py does.  tgt != null fuses  tgt <- tau*p_new + (1-tau)*tgt.
+// two independent segments (encoder, actor) in one launch: same arithmetic per element as adam_kernel
+int drq_adam_flat2(float* p0, const float* g0, float* m0, float* v0, long n0, long step0, float* p1, const float* g1,
+                   float* m1, float* v1, long n1, long step1, double lr, float gscale, hipStream_t st) {
+  if (!p0 || !g0 || !m0 || !v0 || !p1 || !g1 || !m1 || !v1 || n0 <= 0 || n1 <= 0 || step0 <= 0 || step1 <= 0)
+    return DRQ_EARG;
+  AdamSeg2 a{};
+  const long steps[2] = {step0, step1};
+  float* ps[2] = {p0, p1}; const float* gs[2] = {g0, g1}; float* ms[2] = {m0, m1}; float* vs[2] = {v0, v1};
+  const long ns[2] = {n0, n1};
+  for (int i = 0; i < 2; ++i) {
+    const double bc1 = 1.0 - pow(0.9, (double)steps[i]);
+    const double bc2 = 1.0 - pow(0.999, (double)steps[i]);
+    a.p[i] = ps[i]; a.g[i] = gs[i]; a.m[i] = ms[i]; a.v[i] = vs[i]; a.n[i] = ns[i];
+    a.neg_step_size[i] = (float)(-(lr / bc1));
+    a.sqrt_bc2[i] = (float)sqrt(bc2);
+  }
+  a.gscale = gscale;
+  const long nmax = n0 > n1 ? n0 : n1;
+  hipLaunchKernelGGL(adam2_kernel, dim3(grid_for(nmax), 2), dim3(256), 0, st, a);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
 int drq_adam_flat(float* p, const float* g, float* m, float* v, long n, double lr, long step, float gscale,
                   float* tgt, double tau, hipStream_t st) {
   if (!p || !g || !m || !v || n <= 0 || step <= 0) return DRQ_EARG;

@@ -4,6 +4,24 @@
 #include "common.h"
 #include "../../include/drqv2_hip.h"
 
+// elementwise.hip (internal)
+extern "C" int drq_ln_tanh_fwd_multi_ex(int n, const float* const* z, int ldz, const float* const* gamma,
+                                        const float* const* beta, float* const* out, const int* ldo,
+                                        float* const* xhat, float* const* rstd, int rows, int F,
+                                        const float* const* tail, const int* tail_ld, int tail_n, hipStream_t st);
+extern "C" int drq_actor_loss_ex(const float* q1, const float* q2, const float* a, long lda, const float* mu, float std,
+                                 float* dq1, float* dq2, float* sums, int B, int A, float inv_global_B,
+                                 float* sums_host, unsigned seq, hipStream_t st);
+extern "C" int drq_adam_flat2(float* p0, const float* g0, float* m0, float* v0, long n0, long step0, float* p1,
+                              const float* g1, float* m1, float* v1, long n1, long step1, double lr, float gscale,
+                              hipStream_t st);
+// conv.hip (internal)
+int drq_conv3x3_wgrad_partial(const float* x, const float* dy, int nb, int cin, int hin, int stride, long dy_bs,
+                              long dy_cs, long dy_rs, long dy_off, float* part, size_t part_bytes, int* nblocks,
+                              hipStream_t st);
+int drq_conv3x3_wgrad_reduce_multi(int n, const float* const* part, const int* nblocks, const int* cin,
+                                   float* const* dw, float* const* db, hipStream_t st);
+
 namespace {
 
 constexpr long R = 32L * 35 * 35;   // repr_dim (drqv2.py:53)
@@ -281,7 +299,15 @@ int phase_critic_heads(const Ctx& c) {
     const int ldo[4] = {FA, F, F, FA};
     float* xh[4] = {c.ws(W_XHAT_C), c.ws(W_XHAT_A), nullptr, nullptr};
     float* rs[4] = {c.ws(W_RSTD_C), c.ws(W_RSTD_A), nullptr, nullptr};
-    CK(drq_ln_tanh_fwd_multi(4, zz, F, gm, bt, out, ldo, xh, rs, B, F, st));
+    // the critic's [h, action] input: the action columns ride along with problem 0 (drqv2.py:106)
+    const float* tail[4] = {s->action, nullptr, nullptr, nullptr};
+    const int tld[4] = {A, 0, 0, 0};
+    if (A <= 64) {
+      CK(drq_ln_tanh_fwd_multi_ex(4, zz, F, gm, bt, out, ldo, xh, rs, B, F, tail, tld, A, st));
+    } else {
+      CK(drq_ln_tanh_fwd_multi(4, zz, F, gm, bt, out, ldo, xh, rs, B, F, st));
+      CK(drq_copy_cols(s->action, A, c.ws(W_HA_C) + F, FA, B, A, st));
+    }
   }
   // policy MLP once on the 2B stacked rows
   CK(policy_forward(c, hrows, 2 * B, c.ws(W_P1), c.ws(W_P2), c.ws(W_P3)));
@@ -289,7 +315,6 @@ int phase_critic_heads(const Ctx& c) {
   // target: a' ~ TruncN(actor(next)), y = r + d*min Q_target(next, a')   (:180-186);  critic(obs, action) (:188)
   CK(drq_trunc_normal_sample(c.ws(W_P3) + (long)B * A, s->noise_critic, s->std, s->clip, 1, nullptr,
                              c.ws(W_HA_T) + F, FA, B, A, st));
-  CK(drq_copy_cols(s->action, A, c.ws(W_HA_C) + F, FA, B, A, st));
   {
     const HeadOff* nets[2] = {&tg, &cr};
     const float* ha[2] = {c.ws(W_HA_T), c.ws(W_HA_C)};
@@ -348,19 +373,27 @@ int phase_conv_backward(const Ctx& c) {
   hipStream_t st = c.st;
   const int dyid[4] = {W_DY1, W_DY2, W_DY3, W_DY4};
   const int actid[4] = {W_AUG, W_ACT1, W_ACT2, W_ACT3};   // layer inputs
+  // partial sums of the four weight gradients go to four quarters of the conv workspace; ONE reduction launch
+  // at the end turns them into dW/db (nothing reads those before the optimiser step)
   float* cws = c.ws(W_CONV_WS);
-  const size_t cws_bytes = drq_conv3x3_wgrad_ws_bytes();
+  const size_t quarter = drq_conv3x3_wgrad_ws_bytes() / 4;
+  const float* parts[4];
+  int nblk[4], cins[4];
+  float *dws[4], *dbs[4];
   for (int l = 3; l >= 0; --l) {
     const int hin = kEncH[l], hout = kEncH[l + 1], hp = hout + 4;
     const float* dy = c.ws(dyid[l]);
-    CK(drq_conv3x3_wgrad(c.ws(actid[l]), dy, c.g(P.enc_w[l]), c.g(P.enc_b[l]), B, l == 0 ? C : 32, hin, l == 0 ? 2 : 1,
-                         32L * hp * hp, (long)hp * hp, hp, 2L * hp + 2, cws, cws_bytes, st));
+    float* part = cws + (size_t)l * (quarter / sizeof(float));
+    CK(drq_conv3x3_wgrad_partial(c.ws(actid[l]), dy, B, l == 0 ? C : 32, hin, l == 0 ? 2 : 1, 32L * hp * hp,
+                                 (long)hp * hp, hp, 2L * hp + 2, part, quarter, &nblk[l], st));
+    parts[l] = part; cins[l] = l == 0 ? C : 32; dws[l] = c.g(P.enc_w[l]); dbs[l] = c.g(P.enc_b[l]);
     if (l >= 1) {
       const int hpi = hin + 4;   // padded size of the next (shallower) gradient buffer
       CK(drq_conv3x3_dgrad(dy, c.p(P.enc_w[l]), c.ws(actid[l]), c.ws(dyid[l - 1]), B, hout, 32L * hpi * hpi,
                            (long)hpi * hpi, hpi, 2L * hpi + 2, st));
     }
   }
+  CK(drq_conv3x3_wgrad_reduce_multi(4, parts, nblk, cins, dws, dbs, st));
   return 0;
 }
 
@@ -413,9 +446,9 @@ int phase_actor_forward(const Ctx& c) {
     CK(q_forward(c, 1, nets, ha, h1, h2, q));
   }
   const float invB = 1.0f / (float)s->global_B;
-  CK(drq_actor_loss(c.ws(W_TQ), c.ws(W_TQ) + B, c.ws(W_HA_C2) + F, FA, c.ws(W_MU_O), s->std, c.ws(W_DQ),
-                    c.ws(W_DQ) + B, s->sums, B, A, invB, st));
-  if (s->sums_host) CK(publish_sums(s->sums, s->sums_host, (unsigned)s->step_actor, st));
+  // the loss kernel also publishes the eight sums to the host mirror when one is given
+  CK(drq_actor_loss_ex(c.ws(W_TQ), c.ws(W_TQ) + B, c.ws(W_HA_C2) + F, FA, c.ws(W_MU_O), s->std, c.ws(W_DQ),
+                       c.ws(W_DQ) + B, s->sums, B, A, invB, s->sums_host, (unsigned)s->step_actor, st));
   return 0;
 }
 
@@ -532,8 +565,14 @@ int drq_update_phase(const DrqStep* s, int phase) {
   if (phase == 5 || phase == 0 || phase == -1) CK(phase_conv_backward(c));
   if (phase == 6 || phase == 1 || phase == -1) CK(phase_actor_forward(c));
   if (phase == 7 || phase == 1 || phase == -1) CK(phase_actor_backward(c));
-  if (phase == 8 || phase == 2 || phase == -1) CK(phase_encoder_opt(c));
-  if (phase == 9 || phase == 2 || phase == -1) CK(phase_actor_opt(c));
+  if (phase == 2 || phase == -1) {          // both optimiser steps in one launch
+    const ParamLayout& P = c.P;
+    CK(drq_adam_flat2(c.p(P.seg[0]), c.g(P.seg[0]), s->adam_m + P.seg[0], s->adam_v + P.seg[0], P.seg[1] - P.seg[0],
+                      s->step_enc, c.p(P.seg[4]), c.g(P.seg[4]), s->adam_m + P.seg[4], s->adam_v + P.seg[4],
+                      P.seg[5] - P.seg[4], s->step_actor, s->lr, s->gscale, c.st));
+  }
+  if (phase == 8) CK(phase_encoder_opt(c));
+  if (phase == 9) CK(phase_actor_opt(c));
   return 0;
 }
 
