@@ -133,8 +133,12 @@ def main():
         "last_metrics": metrics,
     }
 
-    if rank == 0 and not args.no_roofline:
-        out["roofline"] = roofline_conv(agent, B_local)
+    if not args.no_roofline:
+        # every rank runs it (the updates inside carry the data-parallel collectives); rank 0 reports
+        roof = roofline_conv(agent, B_local, it, step)
+        agent.flush()
+        if rank == 0:
+            out["roofline"] = roof
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.task, B_local)
     if rank == 0:
@@ -145,39 +149,54 @@ def main():
         dist.destroy_process_group()
 
 
-def roofline_conv(agent, B):
-    """conv3x3_kernel<32,41,1>: its two launches per update (conv2 forward on 2B frames, conv3 dgrad on B),
-    timed with events on the stream they are launched on (torch's current stream)."""
-    from drqv2_amd import ops
+# HBM-side bytes per launch of the two launches of conv3x3_kernel<32,41,1> at B = 256, from separate rocprofv3
+# --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (profiles/r01_conv_traffic_pmc.txt, tools/pmc_traffic.sh):
+# (2 * FETCH_SIZE + WRITE_SIZE) * 1024, the factor 2 being the guide's gfx950 correction of FETCH_SIZE.
+CONV_TRAFFIC_KB_B256 = {"conv2_fwd_2B": (68048.2, 106558.5), "conv3_dgrad_B": (63133.0, 54238.4)}
+TRAFFIC_NOTE = ("bytes per launch, mean of the two launches, (2*FETCH_SIZE+WRITE_SIZE)*1024 from separate --pmc passes "
+                "at B=256 (profiles/r01_conv_traffic_pmc.txt); algorithmic bytes are 210 MB (fwd) / 155 MB (dgrad); the "
+                "x2 on FETCH_SIZE is calibrated for 16-byte lane loads, this kernel uses 12-byte ones: the uncorrected "
+                "sum is 179 / 120 MB")
+
+
+def roofline_conv(agent, B, it, step):
+    """conv3x3_kernel<32,41,1>: its two launches per update (conv2 forward on 2B frames, conv3 dgrad on B), timed
+    IN the update with HIP events the library records around those two launches on the stream they run on
+    (DrqStep.timing_events).  In isolation, back to back, the same launches run ~10 % slower (the chip holds a
+    lower clock under an MFMA-only load than inside the update's mix of kernels), and rocprofv3's per-kernel
+    average of the bench agrees with the in-update figure, not with the isolated one."""
     eng = agent._engine
-    act1 = eng.ws_view("ACT1", B, (2 * B, 32, 41, 41))
-    dy3 = eng.ws_view("DY3", B, (B, 32, 41, 41))
-    act2 = eng.ws_view("ACT2", B, (2 * B, 32, 39, 39))[:B]
-    w = agent.encoder.convnet[2].weight.data
-    b = agent.encoder.convnet[2].bias.data
-    w3 = agent.encoder.convnet[4].weight.data
-    reps = 20
-    for _ in range(3):
-        ops.conv3x3_fwd(act1, w, b, 1)
-        ops.conv3x3_dgrad(dy3, w3, act2)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    for e in ev:
+        e.record()                     # torch creates the hipEvent_t at the first record
     torch.cuda.synchronize()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * reps + 1)]
-    ev[0].record()
-    for i in range(reps):
-        ops.conv3x3_fwd(act1, w, b, 1)
-        ev[2 * i + 1].record()
-        ops.conv3x3_dgrad(dy3, w3, act2)
-        ev[2 * i + 2].record()
-    torch.cuda.synchronize()
-    t_f = sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(reps)) / reps * 1e-3
-    t_d = sum(ev[2 * i + 1].elapsed_time(ev[2 * i + 2]) for i in range(reps)) / reps * 1e-3
+    eng.set_timing_events(ev)
+    t_f, t_d, n = 0.0, 0.0, 0
+    try:
+        for u in range(24):
+            agent.update(it, step)
+            step += 2
+            torch.cuda.synchronize()   # the events of THIS update have been reached before they are re-recorded
+            if u >= 4:
+                t_f += ev[0].elapsed_time(ev[1]) * 1e-3
+                t_d += ev[2].elapsed_time(ev[3]) * 1e-3
+                n += 1
+    finally:
+        eng.set_timing_events(None)
+    t_f /= n
+    t_d /= n
+    traffic = None
+    if B == 256:
+        traffic = sum((2 * f + w) * 1024 for f, w in CONV_TRAFFIC_KB_B256.values()) / len(CONV_TRAFFIC_KB_B256)
     fl_f = 2 * 32 * 288 * (2 * B) * 39 * 39
     fl_d = 2 * 32 * 288 * B * 39 * 39
     ach = (fl_f + fl_d) / (t_f + t_d) / 1e12
     return {"kernel": "conv3x3_kernel<32,41,1>", "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS,
-            "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "traffic": None,
+            "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "traffic": traffic,
+            "traffic_note": TRAFFIC_NOTE if traffic is not None else None,
             "avg_launch_us": 0.5e6 * (t_f + t_d), "launch_us": {"conv2_fwd_2B": 1e6 * t_f, "conv3_dgrad_B": 1e6 * t_d},
-            "alg_gflop_per_launch": {"conv2_fwd_2B": fl_f / 1e9, "conv3_dgrad_B": fl_d / 1e9}}
+            "alg_gflop_per_launch": {"conv2_fwd_2B": fl_f / 1e9, "conv3_dgrad_B": fl_d / 1e9},
+            "timing": "hipEvent pairs recorded by the library around the two launches inside 20 update() calls"}
 
 
 def cpu_baseline(task, B):

@@ -28,6 +28,7 @@ class DrqStep(C.Structure):
         ("gscale", C.c_float),
         ("stream", stream_t),
         ("sums_host", c_float_p),
+        ("timing_events", C.POINTER(C.c_void_p)),
     ]
 
 
@@ -92,7 +93,7 @@ def load():
         fn = getattr(lib, name)       # AttributeError = ABI mismatch, also loud
         fn.restype = res
         fn.argtypes = args
-    if lib.drq_abi_version() != 2:
+    if lib.drq_abi_version() != 3:
         raise DrqError("libdrqv2_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

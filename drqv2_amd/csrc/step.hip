@@ -200,14 +200,18 @@ struct Ctx {
   }
 };
 
-int encoder_forward(const Ctx& c, const float* x, int nb, float* a1, float* a2, float* a3, float* a4) {
+int encoder_forward(const Ctx& c, const float* x, int nb, float* a1, float* a2, float* a3, float* a4,
+                    bool timed = false) {
   const ParamLayout& P = c.P;
   float* outs[4] = {a1, a2, a3, a4};
   const float* in = x;
+  void* const* ev = timed ? c.s->timing_events : nullptr;
   for (int l = 0; l < 4; ++l) {
     const int hin = kEncH[l], hout = kEncH[l + 1];
+    if (ev && l == 1 && hipEventRecord((hipEvent_t)ev[0], c.st) != hipSuccess) return DRQ_EARG;
     CK(drq_conv3x3_fwd(in, c.p(P.enc_w[l]), c.p(P.enc_b[l]), outs[l], nb, l == 0 ? c.s->C : 32, hin, l == 0 ? 2 : 1,
                        1, 32L * hout * hout, (long)hout * hout, hout, 0, c.st));
+    if (ev && l == 1 && hipEventRecord((hipEvent_t)ev[1], c.st) != hipSuccess) return DRQ_EARG;
     in = outs[l];
   }
   return 0;
@@ -265,7 +269,7 @@ int phase_encode(const Ctx& c) {
   CK(drq_aug_fwd(s->obs, s->shift_obs, s->base_grid, aug, B, C, 84, 4, 1, st));
   CK(drq_aug_fwd(s->next_obs, s->shift_next, s->base_grid, aug + (long)B * C * 84 * 84, B, C, 84, 4, 1, st));
   // encoder on both views in one pass (:244-246)
-  CK(encoder_forward(c, aug, 2 * B, c.ws(W_ACT1), c.ws(W_ACT2), c.ws(W_ACT3), c.ws(W_FEAT)));
+  CK(encoder_forward(c, aug, 2 * B, c.ws(W_ACT1), c.ws(W_ACT2), c.ws(W_ACT3), c.ws(W_FEAT), true));
   return 0;
 }
 
@@ -389,8 +393,11 @@ int phase_conv_backward(const Ctx& c) {
     parts[l] = part; cins[l] = l == 0 ? C : 32; dws[l] = c.g(P.enc_w[l]); dbs[l] = c.g(P.enc_b[l]);
     if (l >= 1) {
       const int hpi = hin + 4;   // padded size of the next (shallower) gradient buffer
+      void* const* ev = s->timing_events;
+      if (ev && l == 2 && hipEventRecord((hipEvent_t)ev[2], st) != hipSuccess) return DRQ_EARG;
       CK(drq_conv3x3_dgrad(dy, c.p(P.enc_w[l]), c.ws(actid[l]), c.ws(dyid[l - 1]), B, hout, 32L * hpi * hpi,
                            (long)hpi * hpi, hpi, 2L * hpi + 2, st));
+      if (ev && l == 2 && hipEventRecord((hipEvent_t)ev[3], st) != hipSuccess) return DRQ_EARG;
     }
   }
   CK(drq_conv3x3_wgrad_reduce_multi(4, parts, nblk, cins, dws, dbs, st));
@@ -531,7 +538,7 @@ int check_step(const DrqStep* s) {
 
 extern "C" {
 
-int drq_abi_version(void) { return 2; }
+int drq_abi_version(void) { return 3; }
 
 int drq_param_layout(int C, int A, int F, int H, long* out, int cap) {
   if (!out || cap < DRQ_PARAM_LAYOUT_LEN || C <= 0 || A <= 0 || F <= 0 || H <= 0) return DRQ_EARG;

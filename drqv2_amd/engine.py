@@ -110,6 +110,7 @@ class StepEngine:
         self._pending = None      # (all-reduce handle, descriptor, tensors kept alive) of a deferred Adam(actor)
         self._pending_enc = None  # the same for Adam(encoder)
         self.global_metrics = False   # data parallel: all-reduce the metric sums (else: this rank's shard)
+        self._timing_array = None # ctypes array of 4 hipEvent_t (set_timing_events)
         self._side = None         # side stream of the metric-sums exchange
         self._side_busy = False
         self.world = 1
@@ -177,6 +178,15 @@ class StepEngine:
         import torch.distributed as dist
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
+    def set_timing_events(self, events):
+        """bench.py instrumentation: 4 torch.cuda.Event(enable_timing=True), each recorded once already (so that
+        torch has created the hipEvent_t), or None.  See DrqStep.timing_events."""
+        if events is None:
+            self._timing_array = None
+            return
+        arr = (ctypes.c_void_p * 4)(*[int(e.cuda_event) for e in events])
+        self._timing_array = arr
+
     def _side_stream(self):
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
@@ -231,6 +241,7 @@ class StepEngine:
         d.gscale = 1.0
         d.stream = torch.cuda.current_stream().cuda_stream
         d.sums_host = ptr(self.sums_host) if (self.pg is None and self.sums_host is not None) else None
+        d.timing_events = self._timing_array      # None, or 4 hipEvent_t for bench.py's roofline
         return d
 
     def update(self, obs, action, reward, discount, next_obs, shift_obs, shift_next, noise_critic, noise_actor, std,

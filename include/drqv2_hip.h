@@ -150,6 +150,10 @@ typedef struct {
                               * reads the metrics (drqv2.py:191-198,218-223: the .item() calls) by polling slot 8
                               * instead of draining the stream.  Single-GPU only: with data parallelism the sums
                               * are partial until the host has all-reduced them. */
+  void* const* timing_events; /* optional (may be NULL): host array of 4 hipEvent_t created with timing enabled.
+                              * Instrumentation for bench.py's roofline: [0],[1] are recorded on `stream` right
+                              * before / after the conv2 forward launch of phase 3, [2],[3] around the conv3 dgrad
+                              * launch of phase 5 (both are conv3x3_kernel<32,41,1>). */
 } DrqStep;
 
 /* Parameter arena: tensors in parameters() order of encoder, critic, actor, critic_target, each start

@@ -115,7 +115,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert set(_lib.PROTOTYPES) == declared
-    assert lib.drq_abi_version() == 2
+    assert lib.drq_abi_version() == 3
     # layout entry points are host-only and callable without a GPU
     lay = _lib.param_layout(9, 6, 50, 1024)
     assert lay["seg"]["enc"][0] == 0 and lay["total"] == lay["seg"]["target"][1]
