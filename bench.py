@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--strong", action="store_true", help="split ONE --batch over the GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--host-batch", action="store_true",
+                    help="the replay iterator yields pinned HOST tensors (the reference boundary): every update "
+                         "pays the H2D copy of its batch.  Reported for DESIGN.md section 6; never the headline value")
     ap.add_argument("--dp-schedule", action="store_true",
                     help="development: run the data-parallel schedule on a one-rank RCCL group (N=1 only)")
     args = ap.parse_args()
@@ -87,7 +90,8 @@ def main():
     agent = drqv2.DrQV2Agent((9, 84, 84), (A,), dev, lr, F, H, 0.01, 2000, 2, sched, 0.3, True)
     if use_dp:
         agent.enable_data_parallel(batch_is_global=False)
-    batch = tuple(t.to(dev) for t in synth.make_batch(B_local, A, 9, seed=rank, smooth=True))
+    batch = synth.make_batch(B_local, A, 9, seed=rank, smooth=True)
+    batch = tuple(t.pin_memory() for t in batch) if args.host_batch else tuple(t.to(dev) for t in batch)
 
     def replay():
         while True:
@@ -123,7 +127,7 @@ def main():
         "metric": "agent updates/sec (batch=256, 9x84x84 obs)", "value": value, "unit": "updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32", "data": "synthetic" + (" (batch copied host->device every update)" if args.host_batch else ""),
         "config": {"workload": f"{args.task} batch_size={B_local}/GPU ({B_global} global) 9x84x84 u8 obs, A={A}, "
                                f"feature_dim={F}, hidden_dim={H}, fp32, use_tb=True",
                    "parallelism": f"dp{world}", "global_batch": B_global},

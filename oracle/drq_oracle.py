@@ -135,14 +135,19 @@ def aug_integer_crop(x, shift_xy, pad=4):
 # --------------------------------------------------------------------------
 # networks (functional): drqv2.py:48-121
 # --------------------------------------------------------------------------
-def encoder_forward(p, obs, return_acts=False, normalized=False):
-    """p: dict with ENC_KEYS.  obs: [B,C,84,84] float (0..255 scale; already /255-0.5 if normalized)."""
+def encoder_forward(p, obs, return_acts=False, normalized=False, relu_masks=None):
+    """p: dict with ENC_KEYS.  obs: [B,C,84,84] float (0..255 scale; already /255-0.5 if normalized).
+    relu_masks (tests only): four boolean tensors that replace the ReLU decisions of the four layers.  ReLU makes
+    the gradient a discontinuous function of the pre-activations: an implementation that rounds differently
+    flips the sign of a few near-zero pre-activations among millions, and each flip is an O(1) change of that
+    element's gradient path (1e-3 normwise at batch 40-64).  With the decisions of the implementation under
+    test injected, the remaining difference is rounding only."""
     x = obs if normalized else obs / 255.0 - 0.5                 # drqv2.py:64
     acts = [x]
     for li, i in enumerate((0, 2, 4, 6)):
         x = F.conv2d(x, p[f"convnet.{i}.weight"], p[f"convnet.{i}.bias"],
                      stride=2 if li == 0 else 1)
-        x = torch.relu(x)
+        x = torch.relu(x) if relu_masks is None else x * relu_masks[li].to(x.dtype)
         acts.append(x)
     feat = x.reshape(x.shape[0], -1)                             # drqv2.py:66
     return (feat, acts) if return_acts else feat
@@ -312,7 +317,7 @@ class OracleAgent:
 
     # -- the hot path ----------------------------------------------------
     def update(self, batch, step, shifts_obs, shifts_next, noise_critic, noise_actor,
-               aug_base=None, aug_override=None, enc_in_override=None, keep=False):
+               aug_base=None, aug_override=None, enc_in_override=None, keep=False, relu_masks=None):
         """batch = (obs u8 [B,C,84,84], action [B,A], reward [B,1], discount [B,1],
         next_obs u8).  Returns the 8-key metrics dict of drqv2.py (python floats)."""
         if step % self.update_every_steps != 0:
@@ -338,7 +343,8 @@ class OracleAgent:
 
         req = lambda d: OrderedDict((k, v.detach().requires_grad_(True)) for k, v in d.items())
         enc, critic = req(self.enc), req(self.critic)
-        feat, acts = encoder_forward(enc, obs_a, return_acts=True, normalized=normalized)   # :244
+        feat, acts = encoder_forward(enc, obs_a, return_acts=True, normalized=normalized,
+                                     relu_masks=relu_masks)                                 # :244
         with torch.no_grad():
             feat_next = encoder_forward(self.enc, next_a, normalized=normalized)            # :245-246
         metrics["batch_reward"] = reward.mean().item()

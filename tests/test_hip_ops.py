@@ -217,6 +217,32 @@ def test_gemm_batched_wgrad_with_fused_bias_grad(ops, Brows, N, K, n):
         assert nerr(r, dy.double().sum(0)) <= 3e-6
 
 
+@pytest.mark.parametrize("cin,hin,stride,nb", [(9, 84, 2, 256), (32, 41, 1, 512), (32, 39, 1, 256), (32, 37, 1, 96)])
+def test_conv_kernels_at_training_batch_sizes(ops, cin, hin, stride, nb):
+    """Forward, dgrad and wgrad at the batch sizes of the training step, where a wave walks several pixel tiles
+    (delayed stores, prefetch across tiles) and a wgrad wave several output rows (rolling row tiles) -- paths the
+    small cases above never reach.  Reference: torch's own convolution on the GPU in fp64."""
+    import torch.nn.functional as Fn
+    g = torch.Generator(device="cuda").manual_seed(11)
+    rn = lambda *sh: torch.randn(*sh, device="cuda", generator=g)
+    gerr = lambda a, b: float((a.double() - b).norm() / b.norm())
+    hout = (hin - 3) // stride + 1
+    x, w, b = rn(nb, cin, hin, hin), rn(32, cin, 3, 3) * 0.1, rn(32) * 0.1
+    y = ops.conv3x3_fwd(x, w, b, stride)
+    assert gerr(y, torch.relu(Fn.conv2d(x.double(), w.double(), b.double(), stride=stride))) <= 2e-6
+    dy = rn(nb, 32, hout, hout)
+    dy_pad = torch.zeros(nb, 32, hout + 4, hout + 4, device="cuda")
+    dy_pad[:, :, 2:-2, 2:-2] = dy
+    dw, db = ops.conv3x3_wgrad(x, dy_pad[:, :, 2:-2, 2:-2], stride)
+    xd, wd, bd = (t.double().requires_grad_(True) for t in (x, w, b))
+    gx, gw, gb = torch.autograd.grad(Fn.conv2d(xd, wd, bd, stride=stride), (xd, wd, bd), dy.double())
+    assert gerr(dw, gw) <= 3e-6 and gerr(db, gb) <= 3e-6
+    if stride == 1:
+        mask = rn(nb, 32, hin, hin)
+        dx = ops.conv3x3_dgrad(dy_pad, w, mask)
+        assert gerr(dx, gx * (mask.double() > 0)) <= 2e-6
+
+
 @pytest.mark.parametrize("M,K,hw", [(256, 50, 35), (8, 50, 35), (70, 100, 12), (33, 21, 16)])
 def test_skinny_trunk_dgrad_matches_generic_path_and_fp64(ops, M, K, hw):
     """dX = (dz W) * (mask > 0) for the trunk shape (short K, N = 32*hw*hw): the dedicated kernel (automatic
