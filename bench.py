@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--host-batch", action="store_true",
                     help="the replay iterator yields pinned HOST tensors (the reference boundary): every update "
                          "pays the H2D copy of its batch.  Reported for DESIGN.md section 6; never the headline value")
+    ap.add_argument("--device-replay", action="store_true",
+                    help="batches come from the device-resident replay (drq_nstep_gather, index draws on the host) "
+                         "instead of one fixed resident batch: the SURVEY 8f rank-2 path, reported in DESIGN.md")
     ap.add_argument("--dp-schedule", action="store_true",
                     help="development: run the data-parallel schedule on a one-rank RCCL group (N=1 only)")
     args = ap.parse_args()
@@ -98,6 +101,20 @@ def main():
             yield batch
 
     it = replay()
+    if args.device_replay:
+        import numpy as np
+        from drqv2_amd.replay import DeviceReplay
+        store = DeviceReplay(4096, (9, 84, 84), A, 3, 0.99, dev, seed=rank)
+        obs_pool = batch[0].cpu().numpy()
+        r = np.random.RandomState(rank)
+        for e in range(16):                          # 16 episodes of 200 steps drawn from the synthetic frames
+            T1 = 201
+            store.add_episode({"observation": obs_pool[r.randint(0, obs_pool.shape[0], T1)],
+                               "action": r.uniform(-1, 1, (T1, A)).astype(np.float32),
+                               "reward": r.randn(T1, 1).astype(np.float32),
+                               "discount": np.ones((T1, 1), np.float32)})
+        store.batch_size = B_local
+        it = iter(store)
     step = 0
     for _ in range(args.warmup):
         agent.update(it, step)
@@ -127,7 +144,8 @@ def main():
         "metric": "agent updates/sec (batch=256, 9x84x84 obs)", "value": value, "unit": "updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic" + (" (batch copied host->device every update)" if args.host_batch else ""),
+        "dtype": "f32", "data": "synthetic" + (" (batch copied host->device every update)" if args.host_batch else "")
+                                + (" (batches assembled by the device replay)" if args.device_replay else ""),
         "config": {"workload": f"{args.task} batch_size={B_local}/GPU ({B_global} global) 9x84x84 u8 obs, A={A}, "
                                f"feature_dim={F}, hidden_dim={H}, fp32, use_tb=True",
                    "parallelism": f"dp{world}", "global_batch": B_global},

@@ -61,6 +61,7 @@ PROTOTYPES = {
     "drq_ema_flat": (I, [P, P, L, D, P]),
     "drq_fill": (I, [P, L, F, P]),
     "drq_u8_normalize": (I, [P, P, L, P]),
+    "drq_nstep_gather": (I, [P, P, P, P, P, I, I, L, I, F, P, P, P, P, P, P]),
     "drq_tanh": (I, [P, P, L, P]),
     "drq_param_layout": (I, [I, I, I, I, C.POINTER(L), I]),
     "drq_step_ws_bytes": (SZ, [I, I, I, I, I]),

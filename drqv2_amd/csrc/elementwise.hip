@@ -522,6 +522,60 @@ __global__ __launch_bounds__(1024) void qout_bwd_kernel(QOutBwdArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Replay sampling on the device (replay_buffer.py:142-160): batch row b is transition pos[b] of a flat store of
+// steps (episodes contiguous): obs = frame[pos-1], next_obs = frame[pos+nstep-1], action = action[pos], and the
+// n-step return in the reference's float32 order:  reward += discount*r[pos+i];  discount *= d[pos+i]*gamma.
+// blockIdx.y = 0 / 1: obs / next_obs frame copy (16-byte pieces); blockIdx.y = 2: the scalars of 256 rows.
+// ------------------------------------------------------------------------------------------------
+struct NstepArgs {
+  const uint8_t* frames;
+  const float* action;
+  const float* reward;
+  const float* discount;
+  const long* pos;
+  uint8_t* obs;
+  uint8_t* next_obs;
+  float* act_out;
+  float* rew_out;
+  float* disc_out;
+  long frame_bytes;   // multiple of 16
+  int B, A, nstep;
+  float gamma;
+};
+
+__global__ void nstep_gather_kernel(NstepArgs a) {
+#pragma clang fp contract(off)
+  const int which = blockIdx.y;
+  if (which < 2) {
+    const int b = blockIdx.x;
+    if (b >= a.B) return;
+    const long p = a.pos[b] + (which == 0 ? -1 : (long)a.nstep - 1);
+    const uint4* src = reinterpret_cast<const uint4*>(a.frames + p * a.frame_bytes);
+    uint4* dst = reinterpret_cast<uint4*>((which == 0 ? a.obs : a.next_obs) + (long)b * a.frame_bytes);
+    const long n16 = a.frame_bytes >> 4;
+    for (long i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+    return;
+  }
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const long p = a.pos[b];
+  for (int j = 0; j < a.A; ++j) a.act_out[(long)b * a.A + j] = a.action[p * a.A + j];
+  float r = 0.f, d = 1.f;
+  for (int i = 0; i < a.nstep; ++i) {
+    // one rounding per operation: the product is pinned in a register before the add (the packed-math
+    // vectoriser otherwise emits v_pk_fma_f32 here, contract(off) notwithstanding)
+    float t = d * a.reward[p + i];
+    asm volatile("" : "+v"(t));
+    r = r + t;
+    float gd = a.discount[p + i] * a.gamma;
+    asm volatile("" : "+v"(gd));
+    d = d * gd;
+  }
+  a.rew_out[b] = r;
+  a.disc_out[b] = d;
+}
+
 inline unsigned grid_for(long n, int block = 256) {
   long g = (n + block - 1) / block;
   const long cap = 8L * drq_num_cus();
@@ -765,6 +819,21 @@ int drq_adam_flat(float* p, const float* g, float* m, float* v, long n, double l
 int drq_ema_flat(const float* p, float* t, long n, double tau, hipStream_t st) {
   if (!p || !t || n <= 0) return DRQ_EARG;
   hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, t, n, (float)tau, (float)(1.0 - tau));
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
+// Device-side replay batch assembly (replay_buffer.py:142-160), see nstep_gather_kernel.
+int drq_nstep_gather(const uint8_t* frames, const float* action, const float* reward, const float* discount,
+                     const long* pos, int B, int A, long frame_bytes, int nstep, float gamma, uint8_t* obs,
+                     float* act_out, float* rew_out, float* disc_out, uint8_t* next_obs, hipStream_t st) {
+  if (!frames || !action || !reward || !discount || !pos || !obs || !act_out || !rew_out || !disc_out || !next_obs)
+    return DRQ_EARG;
+  if (B <= 0 || A <= 0 || nstep <= 0 || frame_bytes <= 0 || frame_bytes % 16) return DRQ_EARG;
+  if (((uintptr_t)frames | (uintptr_t)obs | (uintptr_t)next_obs) & 15) return DRQ_EARG;
+  NstepArgs a{frames, action, reward, discount, pos, obs, next_obs, act_out, rew_out, disc_out, frame_bytes, B, A, nstep,
+              gamma};
+  hipLaunchKernelGGL(nstep_gather_kernel, dim3(B, 3), dim3(256), 0, st, a);
   DRQ_LAUNCH_CHECK();
   return DRQ_OK;
 }

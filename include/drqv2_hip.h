@@ -116,6 +116,17 @@ int drq_ema_flat(const float* p, float* t, long n, double tau, drq_stream_t stre
 int drq_fill(float* p, long n, float v, drq_stream_t stream);
 /* obs/255-0.5 on raw uint8 frames (drqv2.py:64 as reached from act(), drqv2.py:165-166); y = tanh(x) */
 int drq_u8_normalize(const uint8_t* x, float* y, long n, drq_stream_t stream);
+
+/* ---- replay batch assembly on the device (replay_buffer.py:142-160 `_sample`) ----
+ * A flat store of steps in HBM (each episode contiguous, its first step the dummy reset transition):
+ * frames [n][frame_bytes] u8 (frame_bytes % 16 == 0), action [n][A], reward [n], discount [n].
+ * Row b of the batch is the transition at store index pos[b] (device array, the reference's `idx`):
+ *   obs = frames[pos-1], action = action[pos], next_obs = frames[pos+nstep-1],
+ *   reward/discount = the n-step accumulation in the reference's float32 order
+ *   (reward += discount*r[pos+i]; discount *= d[pos+i]*gamma). */
+int drq_nstep_gather(const uint8_t* frames, const float* action, const float* reward, const float* discount,
+                     const long* pos, int B, int A, long frame_bytes, int nstep, float gamma, uint8_t* obs,
+                     float* act_out, float* rew_out, float* disc_out, uint8_t* next_obs, drq_stream_t stream);
 int drq_tanh(const float* x, float* y, long n, drq_stream_t stream);
 
 /* ---- whole-step entry: DrQV2Agent.update (drqv2.py:230-262) ------------------------------------ */

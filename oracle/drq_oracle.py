@@ -394,3 +394,22 @@ class OracleAgent:
                              g_enc=g_enc, g_critic=g_critic, g_actor=g_actor,
                              mu=mu.detach(), a=a.detach(), aq1=aq1.detach(), aq2=aq2.detach())
         return metrics
+
+
+# ------------------------------------------------------------------------------------------------
+# replay sampling (replay_buffer.py:142-160 `_sample`): pinned by tests/golden/nstep.json
+# ------------------------------------------------------------------------------------------------
+def nstep_sample(episode, idx, nstep, gamma):
+    """episode: dict of numpy arrays (observation [T+1,...], action [T+1,A], reward [T+1,1], discount [T+1,1]), idx the
+    reference's index (1-based: 0 is the dummy reset transition).  float32 arithmetic, one rounding per operation,
+    in the reference's order.  Returns (obs, action, reward, discount, next_obs)."""
+    import numpy as np
+    obs = episode["observation"][idx - 1]
+    action = episode["action"][idx]
+    next_obs = episode["observation"][idx + nstep - 1]
+    reward = np.zeros_like(episode["reward"][idx])
+    discount = np.ones_like(episode["discount"][idx])
+    for i in range(nstep):
+        reward = reward + discount * episode["reward"][idx + i]
+        discount = discount * (episode["discount"][idx + i] * np.float32(gamma))
+    return obs, action, reward, discount, next_obs

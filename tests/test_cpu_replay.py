@@ -1,0 +1,93 @@
+"""Host logic of the device-resident replay (drqv2_amd/replay.py, replay_buffer.py drop-in names): placement and
+whole-episode eviction, the sampling ranges of replay_buffer.py:145-150, the storage's episode assembly, and the
+loud failure of batch assembly without a GPU."""
+import numpy as np
+import pytest
+import torch
+
+from drqv2_amd.replay import DeviceReplay
+from drqv2_amd._lib import DrqError
+
+OBS = (1, 4, 4)      # 16-byte frames
+
+
+def episode(T, A=2, seed=0):
+    r = np.random.RandomState(seed)
+    return {"observation": r.randint(0, 256, (T + 1,) + OBS).astype(np.uint8),
+            "action": r.uniform(-1, 1, (T + 1, A)).astype(np.float32),
+            "reward": r.randn(T + 1, 1).astype(np.float32),
+            "discount": np.ones((T + 1, 1), np.float32)}
+
+
+def test_placement_wraps_and_evicts_whole_oldest_episodes():
+    rp = DeviceReplay(20, OBS, 2, nstep=3, discount=0.99, device="cpu", seed=0)
+    assert rp.add_episode(episode(5, seed=1)) == 0          # 6 steps: slots 0..5
+    assert rp.add_episode(episode(7, seed=2)) == 6          # 8 steps: 6..13
+    assert len(rp) == 12 and rp.episodes == [[0, 6], [6, 8]]
+    assert rp.add_episode(episode(4, seed=3)) == 14         # 5 steps: 14..18
+    # 6 steps do not fit behind slot 19: wrap to 0, the oldest episode (slots 0..5) goes
+    assert rp.add_episode(episode(5, seed=4)) == 0
+    assert rp.episodes == [[6, 8], [14, 5], [0, 6]]
+    # the next one overlaps the second-oldest only partly: it is dropped whole
+    assert rp.add_episode(episode(2, seed=5)) == 6
+    assert rp.episodes == [[14, 5], [0, 6], [6, 3]]
+    assert len(rp) == 4 + 5 + 2
+    ep = episode(5, seed=4)
+    assert torch.equal(rp.frames[0:6], torch.from_numpy(ep["observation"].reshape(6, 16)))
+    assert torch.equal(rp.reward[0:6], torch.from_numpy(ep["reward"].reshape(6)))
+    with pytest.raises(ValueError):
+        rp.add_episode(episode(30))
+
+
+def test_sampling_ranges_match_reference_rule():
+    rp = DeviceReplay(64, OBS, 2, nstep=3, discount=0.99, device="cpu", seed=7)
+    rp.add_episode(episode(2, seed=1))       # shorter than nstep: never sampled (the reference would raise on it)
+    s1 = rp.add_episode(episode(3, seed=2))  # exactly nstep: idx can only be 1
+    s2 = rp.add_episode(episode(10, seed=3))
+    pos = rp.draw_positions(4000)
+    in1 = pos[(pos >= s1) & (pos < s1 + 4)] - s1
+    in2 = pos[(pos >= s2) & (pos < s2 + 11)] - s2
+    assert len(in1) + len(in2) == 4000
+    assert set(in1.tolist()) == {1}
+    assert set(in2.tolist()) == set(range(1, 10 - 3 + 2))       # idx in [1, len - nstep + 1]
+    assert abs(len(in1) / 4000 - 0.5) < 0.05                    # episodes uniform, whatever their length
+    with pytest.raises(DrqError):
+        rp.gather(pos[:8])                                      # batch assembly is a HIP kernel: no CPU fallback
+    empty = DeviceReplay(8, OBS, 2, nstep=3, discount=0.99, device="cpu")
+    with pytest.raises(DrqError):
+        empty.draw_positions(4)
+
+
+class _Spec:
+    def __init__(self, name, shape, dtype):
+        self.name, self.shape, self.dtype = name, shape, dtype
+
+
+class _Step(dict):
+    def __init__(self, last, **kw):
+        super().__init__(**kw)
+        self._last = last
+
+    def last(self):
+        return self._last
+
+
+def test_storage_and_loader_dropin_names(tmp_path):
+    import replay_buffer as rb
+    specs = (_Spec("observation", OBS, np.uint8), _Spec("action", (2,), np.float32),
+             _Spec("reward", (1,), np.float32), _Spec("discount", (1,), np.float32))
+    st = rb.ReplayBufferStorage(specs, tmp_path / "buffer")
+    ep = episode(4, seed=9)
+    for t in range(5):
+        st.add(_Step(t == 4, observation=ep["observation"][t], action=ep["action"][t],
+                     reward=float(ep["reward"][t, 0]), discount=1.0))       # scalars are broadcast to the spec shape
+    assert len(st) == 4
+    loader = rb.make_replay_loader(tmp_path / "buffer", 100, 8, 4, False, 3, 0.99, device="cpu")
+    store = rb._REGISTRY[str(tmp_path / "buffer")]["store"]
+    assert store.nstep == 3 and store.A == 2 and store.obs_shape == OBS
+    it = iter(loader)
+    with pytest.raises(DrqError):            # the pending episode is flushed into the store, then the gather needs the GPU
+        next(it)
+    assert store.episodes == [[0, 5]]
+    assert torch.equal(store.frames[:5], torch.from_numpy(ep["observation"].reshape(5, 16)))
+    assert torch.equal(store.action[:5], torch.from_numpy(ep["action"]))

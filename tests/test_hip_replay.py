@@ -1,0 +1,70 @@
+"""Device replay batch assembly (drq_nstep_gather through drqv2_amd.replay / replay_buffer.py) against the oracle's
+restatement of `_sample` (oracle.nstep_sample, pinned by tests/golden/nstep.json): bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+OBS = (9, 84, 84)
+
+
+def episode(T, A, seed):
+    r = np.random.RandomState(seed)
+    d = np.ones((T + 1, 1), np.float32)
+    d[-1] = 0.0 if seed % 2 else 1.0                 # a terminal step with discount 0 in some episodes
+    return {"observation": r.randint(0, 256, (T + 1,) + OBS).astype(np.uint8),
+            "action": r.uniform(-1, 1, (T + 1, A)).astype(np.float32),
+            "reward": r.randn(T + 1, 1).astype(np.float32), "discount": d}
+
+
+@pytest.mark.parametrize("nstep,gamma,A", [(3, 0.99, 6), (1, 0.99, 1), (5, 0.9, 21)])
+def test_batches_match_oracle_bit_for_bit(nstep, gamma, A):
+    from drqv2_amd.replay import DeviceReplay
+    from oracle import drq_oracle as O
+    rp = DeviceReplay(200, OBS, A, nstep, gamma, "cuda", seed=3)
+    eps = {}
+    for i, T in enumerate((5, 17, 9, 30, 12)):
+        e = episode(T, A, seed=10 + i)
+        eps[rp.add_episode(e)] = e
+    B = 96
+    pos = rp.draw_positions(B)
+    obs, act, rew, disc, nxt = (t.cpu().numpy() for t in rp.gather(pos))
+    assert obs.shape == (B,) + OBS and rew.shape == (B, 1) and act.shape == (B, A)
+    for b, p in enumerate(pos.tolist()):
+        start = max(s for s in eps if s <= p)
+        o, a, r, d, n = O.nstep_sample(eps[start], p - start, nstep, gamma)
+        assert np.array_equal(obs[b], o) and np.array_equal(nxt[b], n) and np.array_equal(act[b], a)
+        assert rew[b, 0] == r[0] and disc[b, 0] == d[0], (b, rew[b, 0], r[0])
+
+
+def test_update_consumes_device_batches(tmp_path):
+    """train.py's wiring: storage.add(time_step) ... agent.update(iter(loader), step) with no host copy of the batch"""
+    import drqv2
+    import replay_buffer as rb
+
+    class Spec:
+        def __init__(self, name, shape, dtype):
+            self.name, self.shape, self.dtype = name, shape, dtype
+
+    class Step(dict):
+        def last(self):
+            return self["_last"]
+
+    A = 3
+    specs = (Spec("observation", OBS, np.uint8), Spec("action", (A,), np.float32), Spec("reward", (1,), np.float32),
+             Spec("discount", (1,), np.float32))
+    st = rb.ReplayBufferStorage(specs, tmp_path / "buffer")
+    loader = rb.make_replay_loader(tmp_path / "buffer", 500, 16, 4, False, 3, 0.99, seed=1)
+    for e in range(3):
+        ep = episode(20, A, seed=e)
+        for t in range(21):
+            st.add(Step(observation=ep["observation"][t], action=ep["action"][t], reward=ep["reward"][t],
+                        discount=ep["discount"][t], _last=(t == 20)))
+    assert len(st) == 60
+    ag = drqv2.DrQV2Agent(OBS, (A,), "cuda", 1e-3, 20, 64, 0.01, 2000, 2, "0.2", 0.3, True)
+    it = iter(loader)
+    for step in (0, 2, 4):
+        m = ag.update(it, step)
+        assert all(np.isfinite(v) for v in m.values()) and set(m) >= {"critic_loss", "actor_loss", "batch_reward"}
+    batch = next(it)
+    assert all(t.is_cuda for t in batch) and batch[0].dtype == torch.uint8 and batch[0].shape == (16,) + OBS

@@ -168,3 +168,11 @@ def test_nstep_known_answers():
             d = np.float32(d * np.float32(dis[c["idx"] + i] * c["gamma"]))
         assert float(r) == pytest.approx(c["reward"], rel=1e-6, abs=1e-7)
         assert float(d) == pytest.approx(c["discount"], rel=1e-6, abs=1e-7)
+        # the oracle's restatement of `_sample` (checker of the device replay), bit for bit
+        from oracle import drq_oracle as O
+        T1 = len(rew)
+        ep = {"observation": np.arange(T1, dtype=np.uint8).reshape(T1, 1), "action": np.zeros((T1, 2), np.float32),
+              "reward": rew.reshape(T1, 1), "discount": dis.reshape(T1, 1)}
+        obs, act, r2, d2, nxt = O.nstep_sample(ep, c["idx"], c["nstep"], c["gamma"])
+        assert float(r2[0]) == c["reward"] and float(d2[0]) == c["discount"]
+        assert int(obs[0]) == c["idx"] - 1 and int(nxt[0]) == c["idx"] + c["nstep"] - 1
