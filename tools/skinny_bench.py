@@ -1,4 +1,4 @@
-"""Trunk backward GEMMs: dedicated kernels vs the generic tiled path (dev tool)."""
+"""Trunk backward GEMMs: automatic dispatch (dedicated dgrad kernel) vs the generic tiled path (dev tool)."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
