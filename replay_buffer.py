@@ -44,18 +44,19 @@ class ReplayBufferStorage:
         return self._num_transitions
 
     def add(self, time_step):
+        step = self._current_episode
         for spec in self._data_specs:
-            value = time_step[spec.name]
-            if np.isscalar(value):
-                value = np.full(spec.shape, value, spec.dtype)
-            assert spec.shape == value.shape and spec.dtype == value.dtype
-            self._current_episode[spec.name].append(value)
-        if time_step.last():
-            episode = dict()
-            for spec in self._data_specs:
-                episode[spec.name] = np.array(self._current_episode[spec.name], spec.dtype)
-            self._current_episode = defaultdict(list)
-            self._store_episode(episode)
+            v = time_step[spec.name]
+            if np.isscalar(v):                       # dm_env hands reward / discount over as python scalars
+                v = np.full(spec.shape, v, spec.dtype)
+            if v.shape != spec.shape or v.dtype != spec.dtype:
+                raise AssertionError(f"{spec.name}: got {v.shape} {v.dtype}, the spec says {spec.shape} {spec.dtype}")
+            step[spec.name].append(v)
+        if not time_step.last():
+            return
+        done = {spec.name: np.array(step[spec.name], spec.dtype) for spec in self._data_specs}
+        self._current_episode = defaultdict(list)
+        self._store_episode(done)
 
     def _store_episode(self, episode):
         self._num_episodes += 1

@@ -21,27 +21,26 @@ class eval_mode:
     """Context manager: put models in eval mode, restore the previous flags on exit (utils.py:18-31)."""
 
     def __init__(self, *models):
-        self.models = models
-        self.prev_states = []
+        self._mods = tuple(models)
+        self._flags = ()
 
     def __enter__(self):
-        self.prev_states = [m.training for m in self.models]
-        for m in self.models:
+        self._flags = tuple(m.training for m in self._mods)
+        for m in self._mods:
             m.train(False)
 
     def __exit__(self, *exc):
-        for m, was_training in zip(self.models, self.prev_states):
-            m.train(was_training)
+        for m, flag in zip(self._mods, self._flags):
+            m.train(flag)
         return False
 
 
 def set_seed_everywhere(seed):
-    """utils.py:34-39."""
-    torch.manual_seed(seed)
+    """Seeds python, numpy and torch (all devices) from one integer (utils.py:34-39)."""
+    for seeder in (random.seed, np.random.seed, torch.manual_seed):
+        seeder(seed)
     if torch.cuda.is_available():
         torch.cuda.manual_seed_all(seed)
-    np.random.seed(seed)
-    random.seed(seed)
 
 
 def soft_update_params(net, target_net, tau):
@@ -83,47 +82,38 @@ def weight_init(m):
 
 
 class Until:
-    """True while step < until // action_repeat (utils.py:64-73)."""
+    """True while step < until // action_repeat; always True without a limit (utils.py:64-73)."""
 
     def __init__(self, until, action_repeat=1):
-        self._until = until
-        self._action_repeat = action_repeat
+        self._limit = None if until is None else until // action_repeat
 
     def __call__(self, step):
-        if self._until is None:
-            return True
-        return step < self._until // self._action_repeat
+        return self._limit is None or step < self._limit
 
 
 class Every:
-    """True on every (every // action_repeat)-th step (utils.py:76-87)."""
+    """True on every (every // action_repeat)-th step; never without a period (utils.py:76-87)."""
 
     def __init__(self, every, action_repeat=1):
-        self._every = every
-        self._action_repeat = action_repeat
+        self._period = None if every is None else every // action_repeat
 
     def __call__(self, step):
-        if self._every is None:
-            return False
-        return step % (self._every // self._action_repeat) == 0
+        return self._period is not None and step % self._period == 0
 
 
 class Timer:
-    """Wall-clock helper (utils.py:90-102)."""
+    """Wall-clock helper: reset() -> (seconds since the last reset, seconds since construction) (utils.py:90-102)."""
 
     def __init__(self):
-        now = time.time()
-        self._start_time = now
-        self._last_time = now
+        self._t0 = self._lap = time.time()
 
     def reset(self):
         now = time.time()
-        elapsed = now - self._last_time
-        self._last_time = now
-        return elapsed, now - self._start_time
+        lap, self._lap = now - self._lap, now
+        return lap, now - self._t0
 
     def total_time(self):
-        return time.time() - self._start_time
+        return time.time() - self._t0
 
 
 class TruncatedNormal(pyd.Normal):
@@ -149,8 +139,15 @@ class TruncatedNormal(pyd.Normal):
         return self._clamp(self.loc + noise)
 
 
-_LINEAR = re.compile(r"linear\((.+),(.+),(.+)\)")
-_STEP_LINEAR = re.compile(r"step_linear\((.+),(.+),(.+),(.+),(.+)\)")
+_NUM = r"\s*([^,()]+?)\s*"
+_FORMS = ((re.compile(r"linear\(" + ",".join([_NUM] * 3) + r"\)"), 3),
+          (re.compile(r"step_linear\(" + ",".join([_NUM] * 5) + r"\)"), 5))
+
+
+def _ramp(a, b, t):
+    """a -> b as t goes 0 -> 1, in the reference's floating-point form"""
+    mix = np.clip(t, 0.0, 1.0)
+    return (1.0 - mix) * a + mix * b
 
 
 def schedule(schdl, step):
@@ -159,17 +156,14 @@ def schedule(schdl, step):
         return float(schdl)
     except ValueError:
         pass
-    m = _LINEAR.match(schdl)
-    if m:
-        init, final, duration = (float(g) for g in m.groups())
-        mix = np.clip(step / duration, 0.0, 1.0)
-        return (1.0 - mix) * init + mix * final
-    m = _STEP_LINEAR.match(schdl)
-    if m:
-        init, final1, duration1, final2, duration2 = (float(g) for g in m.groups())
-        if step <= duration1:
-            mix = np.clip(step / duration1, 0.0, 1.0)
-            return (1.0 - mix) * init + mix * final1
-        mix = np.clip((step - duration1) / duration2, 0.0, 1.0)
-        return (1.0 - mix) * final1 + mix * final2
+    for rx, n in _FORMS:
+        m = rx.match(schdl)
+        if m is None:
+            continue
+        v = [float(g) for g in m.groups()]
+        if n == 3:
+            return _ramp(v[0], v[1], step / v[2])
+        if step <= v[2]:
+            return _ramp(v[0], v[1], step / v[2])
+        return _ramp(v[1], v[3], (step - v[2]) / v[4])
     raise NotImplementedError(schdl)
