@@ -88,6 +88,9 @@ struct LnArgs {
   const float* tail[4];   // optional [rows][tail_ld]: copied into out columns [F, F+tail_n) (the [h, action] concat)
   int tail_ld[4];
   int tail_n;
+  const float* part;      // optional: z is not given but split-K partials [n*splitk][rows][F] of the trunk GEMM
+  const float* bias[4];   //           (gemm.hip layout) plus the layer bias; summed in splitk_reduce_kernel's order
+  int splitk;
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -101,14 +104,38 @@ __global__ void ln_tanh_fwd_kernel(LnArgs a) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= a.rows) return;
-  const float* z = a.z[g] + (long)row * a.ldz[g];
   float v[4];
   float s = 0.f;
+  if (a.part) {
+    const long mn = (long)a.rows * a.F;
+    const float* p = a.part + (long)g * a.splitk * mn + (long)row * a.F;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int f = lane + 64 * q;
-    v[q] = f < a.F ? z[f] : 0.f;
-    s += v[q];
+    for (int q = 0; q < 4; ++q) {
+      const int f = lane + 64 * q;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      if (f < a.F) {
+        int k = 0;
+        for (; k + 3 < a.splitk; k += 4) {
+          s0 += p[(long)k * mn + f];
+          s1 += p[(long)(k + 1) * mn + f];
+          s2 += p[(long)(k + 2) * mn + f];
+          s3 += p[(long)(k + 3) * mn + f];
+        }
+        for (; k < a.splitk; ++k) s0 += p[(long)k * mn + f];
+        v[q] = ((s0 + s1) + (s2 + s3)) + (a.bias[g] ? a.bias[g][f] : 0.f);
+      } else {
+        v[q] = 0.f;
+      }
+      s += v[q];
+    }
+  } else {
+    const float* z = a.z[g] + (long)row * a.ldz[g];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int f = lane + 64 * q;
+      v[q] = f < a.F ? z[f] : 0.f;
+      s += v[q];
+    }
   }
   const float mean = wave_sum(s) / (float)a.F;
   float ss = 0.f;
@@ -576,6 +603,173 @@ __global__ void nstep_gather_kernel(NstepArgs a) {
   a.disc_out[b] = d;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Policy output layer Linear(H, A) (drqv2.py:81,86-90), A <= 64.  Forward: one wave per row computes the A dot
+// products (row in registers, W3 rows from L1), adds the bias and -- for rows >= srow0 when a noise table is
+// given -- samples the action (tanh, clipped noise, straight-through clamp: utils.py:117-126) in the same pass.
+// Backward: dpre = (da1+da2)(1-mu^2), then dp2 = (dpre W3)*(p2>0), dW3 = dpre^T p2, db3 = sum dpre in one kernel.
+// Both replace a GEMM with N or M = action_dim (plus split-K reduce and elementwise launches).
+// ------------------------------------------------------------------------------------------------
+struct PolOutArgs {
+  const float* h2;      // [rows][H]
+  const float* w;       // [A][H]
+  const float* b;       // [A]
+  float* p3;            // [rows][A] pre-tanh output
+  const float* noise;   // [rows - srow0][A] or null
+  float* mu_out;        // [rows - srow0][A] or null
+  float* a_out;         // action columns of the critic input, row stride lda_out
+  long lda_out;
+  int rows, H, A, srow0, use_clip;
+  float std, clip;
+};
+
+__global__ void policy_out_kernel(PolOutArgs a) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= a.rows) return;
+  const float* h = a.h2 + (long)row * a.H;
+  float mine = 0.f;
+  if (a.H <= 1024) {
+    // the row in 16 registers; the weights of 2 outputs (32 loads) in flight per round trip
+    float hv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) hv[q] = (lane + 64 * q < a.H) ? h[lane + 64 * q] : 0.f;
+    for (int j = 0; j < a.A; j += 2) {
+      const int j1 = j + 1 < a.A ? j + 1 : j;
+      const float* w0 = a.w + (long)j * a.H;
+      const float* w1 = a.w + (long)j1 * a.H;
+      float x0[16], x1[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int i = min(lane + 64 * q, a.H - 1);      // hv is 0 past H: the clamped weight does not matter
+        x0[q] = w0[i];
+        x1[q] = w1[i];
+      }
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        s0 = __fmaf_rn(hv[q], x0[q], s0);
+        s1 = __fmaf_rn(hv[q], x1[q], s1);
+      }
+      s0 = wave_sum(s0) + a.b[j];
+      s1 = wave_sum(s1) + a.b[j1];
+      if (lane == j) mine = s0;
+      if (lane == j + 1) mine = s1;
+    }
+  } else {
+    for (int j = 0; j < a.A; ++j) {
+      const float* w = a.w + (long)j * a.H;
+      float s0 = 0.f;
+      for (int i = lane; i < a.H; i += 64) s0 = __fmaf_rn(h[i], w[i], s0);
+      const float s = wave_sum(s0) + a.b[j];
+      if (lane == j) mine = s;
+    }
+  }
+  if (lane >= a.A) return;
+  a.p3[(long)row * a.A + lane] = mine;
+  if (a.noise && row >= a.srow0) {
+    const long r = row - a.srow0;
+    const float mu = tanhf(mine);
+    float eps = a.noise[r * a.A + lane] * a.std;
+    if (a.use_clip) eps = fminf(fmaxf(eps, -a.clip), a.clip);
+    const float lo = (float)(-1.0 + 1e-6), hi = (float)(1.0 - 1e-6);
+    if (a.mu_out) a.mu_out[r * a.A + lane] = mu;
+    a.a_out[r * a.lda_out + lane] = fminf(fmaxf(mu + eps, lo), hi);
+  }
+}
+
+struct PolBwdArgs {
+  const float* da1;     // [B][ld]: action-column gradient from Q head 1 (columns col0..col0+A)
+  const float* da2;
+  long ld;
+  int col0;
+  const float* mu;      // [B][A]
+  const float* p2;      // [B][H] post-ReLU input of the layer
+  const float* w;       // [A][H]
+  float* dp2;           // [B][H]
+  float* dw;            // [A][H]
+  float* db;            // [A]
+  int B, H, A;
+};
+
+constexpr int kPolMaxA = 32;
+
+// Workgroup = 64 columns of H x 16 row groups.  dpre[B][A] (tiny) is computed once per workgroup into LDS; the only
+// global stream in the row loop is p2, 16 rows of it in flight per thread.
+template <int AMAX>    // action_dim rounded up to 8 / 16 / 32: the per-output loops are unrolled over it
+__global__ __launch_bounds__(1024) void policy_out_bwd_kernel(PolBwdArgs a) {
+  extern __shared__ float dpre[];           // [B][A], then 16 x 64 floats of reduction scratch
+  float* sm = dpre + a.B * a.A;
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + c;
+  const bool nok = n < a.H;
+  const int nc = nok ? n : a.H - 1;
+  for (int i = threadIdx.x; i < a.B * a.A; i += 1024) {
+    const int m = i / a.A, j = i - m * a.A;
+    const float mv = a.mu[i];
+    dpre[i] = (a.da1[(long)m * a.ld + a.col0 + j] + a.da2[(long)m * a.ld + a.col0 + j]) * (1.f - mv * mv);
+  }
+  float wn[AMAX], acc[AMAX];
+#pragma unroll
+  for (int j = 0; j < AMAX; ++j) {
+    wn[j] = j < a.A ? a.w[(long)j * a.H + nc] : 0.f;
+    acc[j] = 0.f;
+  }
+  __syncthreads();
+  for (int m0 = rg; m0 < a.B; m0 += 16 * 16) {
+    float hv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) hv[u] = a.p2[(long)min(m0 + 16 * u, a.B - 1) * a.H + nc];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int m = m0 + 16 * u;
+      if (m < a.B) {
+        const float* dp = dpre + m * a.A;
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < AMAX; ++j) {
+          if (j < a.A) {
+            const float dv = dp[j];
+            d = __fmaf_rn(dv, wn[j], d);
+            acc[j] = __fmaf_rn(dv, hv[u], acc[j]);
+          }
+        }
+        if (nok) a.dp2[(long)m * a.H + n] = hv[u] > 0.f ? d : 0.f;
+      }
+    }
+  }
+  // dW3: the 16 row groups of a column are summed in order through LDS, one output row at a time
+  for (int j = 0; j < a.A; ++j) {
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < AMAX; ++q)
+      if (q == j) v = acc[q];
+    sm[rg * 64 + c] = v;
+    __syncthreads();
+    if (rg == 0 && nok) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) t += sm[g * 64 + c];
+      a.dw[(long)j * a.H + n] = t;
+    }
+    __syncthreads();
+  }
+  // db3: workgroup 0; row group rg sums its rows of dpre[:, c], the 16 partials are added in order
+  if (blockIdx.x == 0) {
+    float t = 0.f;
+    if (c < a.A)
+      for (int m = rg; m < a.B; m += 16) t += dpre[m * a.A + c];
+    sm[rg * 64 + c] = t;
+    __syncthreads();
+    if (rg == 0 && c < a.A) {
+      float tot = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) tot += sm[g * 64 + c];
+      a.db[c] = tot;
+    }
+  }
+}
+
 inline unsigned grid_for(long n, int block = 256) {
   long g = (n + block - 1) / block;
   const long cap = 8L * drq_num_cus();
@@ -594,6 +788,10 @@ int drq_ln_tanh_fwd_multi_ex(int n, const float* const* z, int ldz, const float*
 int drq_actor_loss_ex(const float* q1, const float* q2, const float* a, long lda, const float* mu, float std,
                       float* dq1, float* dq2, float* sums, int B, int A, float inv_global_B, float* sums_host,
                       unsigned seq, hipStream_t st);
+int drq_ln_tanh_fwd_multi_part(int n, const float* const* z, int ldz, const float* const* gamma,
+                               const float* const* beta, float* const* out, const int* ldo, float* const* xhat,
+                               float* const* rstd, int rows, int F, const float* const* tail, const int* tail_ld,
+                               int tail_n, const float* part, const float* const* bias, int splitk, hipStream_t st);
 
 int drq_aug_fwd(const uint8_t* obs, const float* shift_xy, const float* base_grid, float* out, int n, int c,
                 int hw, int pad, int fuse_norm, hipStream_t st) {
@@ -698,17 +896,31 @@ int drq_ln_tanh_fwd_multi_ex(int n, const float* const* z, int ldz, const float*
                              const float* const* beta, float* const* out, const int* ldo, float* const* xhat,
                              float* const* rstd, int rows, int F, const float* const* tail, const int* tail_ld,
                              int tail_n, hipStream_t st) {
-  if (n <= 0 || n > 4 || !z || !gamma || !beta || !out || !ldo || rows <= 0 || F <= 0 || F > 256) return DRQ_EARG;
+  return drq_ln_tanh_fwd_multi_part(n, z, ldz, gamma, beta, out, ldo, xhat, rstd, rows, F, tail, tail_ld, tail_n,
+                                    nullptr, nullptr, 0, st);
+}
+
+// ... and with the pre-norm input given as split-K partials of the trunk GEMM (z may then be null)
+int drq_ln_tanh_fwd_multi_part(int n, const float* const* z, int ldz, const float* const* gamma,
+                               const float* const* beta, float* const* out, const int* ldo, float* const* xhat,
+                               float* const* rstd, int rows, int F, const float* const* tail, const int* tail_ld,
+                               int tail_n, const float* part, const float* const* bias, int splitk, hipStream_t st) {
+  if (n <= 0 || n > 4 || (!z && !part) || !gamma || !beta || !out || !ldo || rows <= 0 || F <= 0 || F > 256)
+    return DRQ_EARG;
   if (tail && (tail_n <= 0 || tail_n > 64 || !tail_ld)) return DRQ_EARG;
+  if (part && splitk < 1) return DRQ_EARG;
   LnArgs a{};
+  a.part = part;
+  a.splitk = splitk;
   a.tail_n = tail ? tail_n : 0;
   for (int i = 0; i < n && tail; ++i) {
     a.tail[i] = tail[i];
     a.tail_ld[i] = tail_ld[i];
   }
   for (int i = 0; i < n; ++i) {
-    if (!z[i] || !gamma[i] || !beta[i] || !out[i]) return DRQ_EARG;
-    a.z[i] = z[i]; a.gamma[i] = gamma[i]; a.beta[i] = beta[i]; a.out[i] = out[i];
+    if ((!part && !z[i]) || !gamma[i] || !beta[i] || !out[i]) return DRQ_EARG;
+    a.z[i] = z ? z[i] : nullptr; a.gamma[i] = gamma[i]; a.beta[i] = beta[i]; a.out[i] = out[i];
+    a.bias[i] = (part && bias) ? bias[i] : nullptr;
     a.xhat[i] = xhat ? xhat[i] : nullptr;
     a.rstd[i] = rstd ? rstd[i] : nullptr;
     a.ldz[i] = ldz; a.ldo[i] = ldo[i];
@@ -732,6 +944,32 @@ int drq_trunc_normal_sample(const float* pre_tanh, const float* noise, float std
   if (!pre_tanh || !noise || !a_out || B <= 0 || A <= 0) return DRQ_EARG;
   hipLaunchKernelGGL(sample_action_kernel, dim3((B * A + 255) / 256), dim3(256), 0, st, pre_tanh, noise, std, clip,
                      use_clip, mu_out, a_out, lda_out, B, A);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
+// internal (step.hip): policy output layer forward (+ optional action sampling) and backward, see the kernels
+int drq_policy_out_fwd(const float* h2, const float* w, const float* b, float* p3, int rows, int H, int A,
+                       const float* noise, float std, float clip, int use_clip, int srow0, float* mu_out,
+                       float* a_out, long lda_out, hipStream_t st) {
+  if (!h2 || !w || !b || !p3 || rows <= 0 || H <= 0 || A <= 0 || A > 64) return DRQ_EARG;
+  if (noise && (!a_out || srow0 < 0 || srow0 > rows)) return DRQ_EARG;
+  PolOutArgs a{h2, w, b, p3, noise, mu_out, a_out, lda_out, rows, H, A, srow0, use_clip, std, clip};
+  hipLaunchKernelGGL(policy_out_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, a);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
+int drq_policy_out_bwd(const float* da1, const float* da2, long ld, int col0, const float* mu, const float* p2,
+                       const float* w, float* dp2, float* dw, float* db, int B, int H, int A, hipStream_t st) {
+  if (!da1 || !da2 || !mu || !p2 || !w || !dp2 || !dw || !db || B <= 0 || H <= 0 || A <= 0 || A > kPolMaxA)
+    return DRQ_EARG;
+  const size_t lds = ((size_t)B * A + 16 * 64) * sizeof(float);
+  if (lds > 60 * 1024) return DRQ_EARG;
+  PolBwdArgs a{da1, da2, ld, col0, mu, p2, w, dp2, dw, db, B, H, A};
+  if (A <= 8) hipLaunchKernelGGL(policy_out_bwd_kernel<8>, dim3((H + 63) / 64), dim3(1024), lds, st, a);
+  else if (A <= 16) hipLaunchKernelGGL(policy_out_bwd_kernel<16>, dim3((H + 63) / 64), dim3(1024), lds, st, a);
+  else hipLaunchKernelGGL(policy_out_bwd_kernel<32>, dim3((H + 63) / 64), dim3(1024), lds, st, a);
   DRQ_LAUNCH_CHECK();
   return DRQ_OK;
 }

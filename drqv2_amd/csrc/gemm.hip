@@ -345,13 +345,18 @@ __global__ void splitk_reduce_kernel(GemmArgs g) {
   epilogue_store(g, batch, m, n, (s0 + s1) + (s2 + s3));
 }
 
+// set by drq_gemm_batched_partial around one call: keep the split-K partials, the caller reduces them itself
+bool g_leave_partials = false;
+int g_last_splitk = 1;
+
 template <int TM, int TN, bool A_KC, bool B_KC, bool V4, int BK = BK0>
 int launch(const GemmArgs& g, hipStream_t st) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.nbatch * g.splitk);
   hipLaunchKernelGGL((gemm_kernel<TM, TN, A_KC, B_KC, V4, BK>), grid, dim3(256), 0, st, g);
   DRQ_LAUNCH_CHECK();
-  if (g.splitk > 1) {
+  g_last_splitk = g.splitk;
+  if (g.splitk > 1 && !g_leave_partials) {
     const long mn = (long)g.M * g.N;
     dim3 rg((unsigned)((mn + 255) / 256), g.nbatch);
     hipLaunchKernelGGL(splitk_reduce_kernel, rg, dim3(256), 0, st, g);
@@ -444,6 +449,20 @@ int drq_gemm_batched_f32(int nbatch, const float* const* A, long lda, int a_kc, 
   if (tile == 5) return dispatch<1, 1, 64>(g, a_kc, b_kc, v4, st);   // 32x32, k-tile 64 (one barrier per 64 k)
   if (tile == 6) return dispatch<2, 2, 64>(g, a_kc, b_kc, v4, st);   // 64x64, k-tile 64
   return tile == 2 ? dispatch<2, 2>(g, a_kc, b_kc, v4, st) : dispatch<1, 1>(g, a_kc, b_kc, v4, st);
+}
+
+// internal (step.hip): same call, but a split-K result stays in `ws` as partials [nbatch*splitk][M][N] (no bias, no
+// epilogue) and *splitk_out says how many there are per problem; 1 = the result went to C as usual
+int drq_gemm_batched_partial(int nbatch, const float* const* A, long lda, int a_kc, const float* const* B, long ldb,
+                             int b_kc, float* const* C, long ldc, int M, int N, int K, const float* const* bias,
+                             float* ws, size_t ws_bytes, int* splitk_out, hipStream_t st) {
+  g_leave_partials = true;
+  g_last_splitk = 1;
+  const int rc = drq_gemm_batched_f32(nbatch, A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, bias, 0, nullptr, 0, nullptr,
+                                      0, 1, 0, ws, ws_bytes, st);
+  g_leave_partials = false;
+  if (splitk_out) *splitk_out = g_last_splitk;
+  return rc;
 }
 
 // strided-batch form of the same call

@@ -4,7 +4,23 @@
 #include "common.h"
 #include "../../include/drqv2_hip.h"
 
+// gemm.hip / elementwise.hip (internal): trunk GEMM that leaves its split-K partials, LayerNorm that sums them
+extern "C" int drq_gemm_batched_partial(int nbatch, const float* const* A, long lda, int a_kc, const float* const* B,
+                                        long ldb, int b_kc, float* const* C, long ldc, int M, int N, int K,
+                                        const float* const* bias, float* ws, size_t ws_bytes, int* splitk_out,
+                                        hipStream_t st);
+extern "C" int drq_ln_tanh_fwd_multi_part(int n, const float* const* z, int ldz, const float* const* gamma,
+                                          const float* const* beta, float* const* out, const int* ldo,
+                                          float* const* xhat, float* const* rstd, int rows, int F,
+                                          const float* const* tail, const int* tail_ld, int tail_n, const float* part,
+                                          const float* const* bias, int splitk, hipStream_t st);
 // elementwise.hip (internal)
+extern "C" int drq_policy_out_fwd(const float* h2, const float* w, const float* b, float* p3, int rows, int H, int A,
+                                  const float* noise, float std, float clip, int use_clip, int srow0, float* mu_out,
+                                  float* a_out, long lda_out, hipStream_t st);
+extern "C" int drq_policy_out_bwd(const float* da1, const float* da2, long ld, int col0, const float* mu,
+                                  const float* p2, const float* w, float* dp2, float* dw, float* db, int B, int H,
+                                  int A, hipStream_t st);
 extern "C" int drq_ln_tanh_fwd_multi_ex(int n, const float* const* z, int ldz, const float* const* gamma,
                                         const float* const* beta, float* const* out, const int* ldo,
                                         float* const* xhat, float* const* rstd, int rows, int F,
@@ -218,7 +234,10 @@ int encoder_forward(const Ctx& c, const float* x, int nb, float* a1, float* a2, 
 }
 
 // policy MLP (drqv2.py:77-81) on `rows` rows of h -> pre-tanh output p3
-int policy_forward(const Ctx& c, const float* h, int rows, float* p1, float* p2, float* p3) {
+// sample_from >= 0: rows [sample_from, rows) also get their action sampled with `noise` into a_out (the output-layer
+// kernel does both); needs A <= 64, else the output layer is a GEMM and the caller samples separately (returns 1)
+int policy_forward(const Ctx& c, const float* h, int rows, float* p1, float* p2, float* p3, int sample_from = -1,
+                   const float* noise = nullptr, float* a_out = nullptr, long lda_out = 0) {
   const DrqStep* s = c.s;
   const HeadOff& a = c.P.actor;
   const int H = s->H, F = s->F, A = s->A;
@@ -228,7 +247,15 @@ int policy_forward(const Ctx& c, const float* h, int rows, float* p1, float* p2,
   float *y0[1] = {p1}, *y1[1] = {p2}, *y2[1] = {p3};
   CK(c.fwd(1, x0, F, w0, b0, y0, H, rows, H, F, 1));
   CK(c.fwd(1, x1, H, w1, b1, y1, H, rows, H, H, 1));
+  if (A <= 64) {
+    CK(drq_policy_out_fwd(p2, w2[0], b2[0], p3, rows, H, A, sample_from >= 0 ? noise : nullptr, s->std, s->clip, 1,
+                          sample_from >= 0 ? sample_from : 0, nullptr, a_out, lda_out, c.st));
+    return 0;
+  }
   CK(c.fwd(1, x2, H, w2, b2, y2, A, rows, A, H, 0));
+  if (sample_from >= 0)
+    CK(drq_trunc_normal_sample(p3 + (long)sample_from * A, noise, s->std, s->clip, 1, nullptr, a_out, lda_out,
+                               rows - sample_from, A, c.st));
   return 0;
 }
 
@@ -295,7 +322,9 @@ int phase_critic_heads(const Ctx& c) {
     const float* w[4] = {c.p(cr.trunk_w), c.p(ac.trunk_w), c.p(ac.trunk_w), c.p(tg.trunk_w)};
     const float* b[4] = {c.p(cr.trunk_b), c.p(ac.trunk_b), c.p(ac.trunk_b), c.p(tg.trunk_b)};
     float* y[4] = {z4, z4 + (long)B * F, z4 + 2L * B * F, z4 + 3L * B * F};
-    CK(c.fwd(4, x, R, w, b, y, F, B, F, (int)R, 0));
+    // the GEMM leaves its split-K partials in the workspace: the LayerNorm kernel sums them (+ bias) itself
+    int sk = 1;
+    CK(drq_gemm_batched_partial(4, x, R, 1, w, R, 1, y, F, B, F, (int)R, b, c.gemm_ws(), c.gemm_ws_bytes(), &sk, st));
     const float* zz[4] = {y[0], y[1], y[2], y[3]};
     const float* gm[4] = {c.p(cr.ln_g), c.p(ac.ln_g), c.p(ac.ln_g), c.p(tg.ln_g)};
     const float* bt[4] = {c.p(cr.ln_b), c.p(ac.ln_b), c.p(ac.ln_b), c.p(tg.ln_b)};
@@ -306,19 +335,17 @@ int phase_critic_heads(const Ctx& c) {
     // the critic's [h, action] input: the action columns ride along with problem 0 (drqv2.py:106)
     const float* tail[4] = {s->action, nullptr, nullptr, nullptr};
     const int tld[4] = {A, 0, 0, 0};
-    if (A <= 64) {
-      CK(drq_ln_tanh_fwd_multi_ex(4, zz, F, gm, bt, out, ldo, xh, rs, B, F, tail, tld, A, st));
-    } else {
-      CK(drq_ln_tanh_fwd_multi(4, zz, F, gm, bt, out, ldo, xh, rs, B, F, st));
-      CK(drq_copy_cols(s->action, A, c.ws(W_HA_C) + F, FA, B, A, st));
-    }
+    const bool with_tail = A <= 64;
+    CK(drq_ln_tanh_fwd_multi_part(4, zz, F, gm, bt, out, ldo, xh, rs, B, F, with_tail ? tail : nullptr,
+                                  with_tail ? tld : nullptr, with_tail ? A : 0, sk > 1 ? c.gemm_ws() : nullptr, b, sk,
+                                  st));
+    if (!with_tail) CK(drq_copy_cols(s->action, A, c.ws(W_HA_C) + F, FA, B, A, st));
   }
   // policy MLP once on the 2B stacked rows
-  CK(policy_forward(c, hrows, 2 * B, c.ws(W_P1), c.ws(W_P2), c.ws(W_P3)));
+  // ... and, in the output-layer kernel, a' ~ TruncN(actor(next)) for the target (:180-183)
+  CK(policy_forward(c, hrows, 2 * B, c.ws(W_P1), c.ws(W_P2), c.ws(W_P3), B, s->noise_critic, c.ws(W_HA_T) + F, FA));
 
-  // target: a' ~ TruncN(actor(next)), y = r + d*min Q_target(next, a')   (:180-186);  critic(obs, action) (:188)
-  CK(drq_trunc_normal_sample(c.ws(W_P3) + (long)B * A, s->noise_critic, s->std, s->clip, 1, nullptr,
-                             c.ws(W_HA_T) + F, FA, B, A, st));
+  // y = r + d*min Q_target(next, a')   (:184-186);  critic(obs, action) (:188)
   {
     const HeadOff* nets[2] = {&tg, &cr};
     const float* ha[2] = {c.ws(W_HA_T), c.ws(W_HA_C)};
@@ -443,9 +470,14 @@ int phase_actor_forward(const Ctx& c) {
   {
     const float *x[1] = {feat_obs}, *w[1] = {c.p(cr.trunk_w)}, *b[1] = {c.p(cr.trunk_b)};
     float* y[1] = {c.ws(W_Z_C2)};
-    CK(c.fwd(1, x, R, w, b, y, F, B, F, (int)R, 0));
+    int sk = 1;
+    CK(drq_gemm_batched_partial(1, x, R, 1, w, R, 1, y, F, B, F, (int)R, b, c.gemm_ws(), c.gemm_ws_bytes(), &sk, st));
+    const float *zz[1] = {y[0]}, *gm[1] = {c.p(cr.ln_g)}, *bt[1] = {c.p(cr.ln_b)};
+    float* out[1] = {c.ws(W_HA_C2)};
+    const int ldo[1] = {FA};
+    CK(drq_ln_tanh_fwd_multi_part(1, zz, F, gm, bt, out, ldo, nullptr, nullptr, B, F, nullptr, nullptr, 0,
+                                  sk > 1 ? c.gemm_ws() : nullptr, b, sk, st));
   }
-  CK(drq_ln_tanh_fwd(c.ws(W_Z_C2), F, c.p(cr.ln_g), c.p(cr.ln_b), c.ws(W_HA_C2), FA, nullptr, nullptr, B, F, st));
   {
     const HeadOff* nets[1] = {&cr};
     const float* ha[1] = {c.ws(W_HA_C2)};
@@ -482,7 +514,9 @@ int phase_actor_backward(const Ctx& c) {
     CK(c.dgrad(2, dc2c, H, w1, H, dc1, H, B, H, H, t1, H));
     CK(c.dgrad(2, dc1c, H, w0a, FA, da, A, B, A, H, nullptr, 0));     // action columns of layer 1 only
   }
-  CK(drq_actor_dmu(c.ws(W_DA), c.ws(W_DA) + (long)B * A, A, 0, c.ws(W_MU_O), c.ws(W_DPRE), B, A, st));
+  // output layer backward in one kernel (dpre, dW3, db3, dp2) when dpre fits its LDS
+  const bool fused_head = A <= 32 && ((size_t)B * A + 1024) * 4 <= 60 * 1024;
+  if (!fused_head) CK(drq_actor_dmu(c.ws(W_DA), c.ws(W_DA) + (long)B * A, A, 0, c.ws(W_MU_O), c.ws(W_DPRE), B, A, st));
 
   // policy MLP backward (rows [0,B) of the stacked activations are the obs rows)
   {
@@ -492,8 +526,13 @@ int phase_actor_backward(const Ctx& c) {
     const float *w0[1] = {c.p(ac.w[0][0])}, *w1[1] = {c.p(ac.w[0][1])}, *w2[1] = {c.p(ac.w[0][2])};
     float *gw0[1] = {c.g(ac.w[0][0])}, *gw1[1] = {c.g(ac.w[0][1])}, *gw2[1] = {c.g(ac.w[0][2])};
     float *gb0[1] = {c.g(ac.b[0][0])}, *gb1[1] = {c.g(ac.b[0][1])}, *gb2[1] = {c.g(ac.b[0][2])};
-    CK(c.wgrad(1, dpre, A, p2, H, gw2, gb2, B, A, H));
-    CK(c.dgrad(1, dpre, A, w2, H, dp2, H, B, H, A, p2, H));
+    if (fused_head) {
+      CK(drq_policy_out_bwd(c.ws(W_DA), c.ws(W_DA) + (long)B * A, A, 0, c.ws(W_MU_O), p2[0], w2[0], dp2[0], gw2[0],
+                            gb2[0], B, H, A, st));
+    } else {
+      CK(c.wgrad(1, dpre, A, p2, H, gw2, gb2, B, A, H));
+      CK(c.dgrad(1, dpre, A, w2, H, dp2, H, B, H, A, p2, H));
+    }
     CK(c.wgrad(1, dp2c, H, p1, H, gw1, gb1, B, H, H));
     CK(c.dgrad(1, dp2c, H, w1, H, dp1, H, B, H, H, p1, H));
     CK(c.wgrad(1, dp1c, H, h, F, gw0, gb0, B, H, F));
