@@ -161,6 +161,21 @@ __global__ void ln_tanh_fwd_kernel(LnArgs a) {
   if (a.tail[g] && lane < a.tail_n) a.out[g][(long)row * a.ldo[g] + a.F + lane] = a.tail[g][(long)row * a.tail_ld[g] + lane];
 }
 
+// sum of the split-K partial slabs of one GEMM output element, in splitk_reduce_kernel's association
+// (gemm.hip): p points at the element in slab 0, consecutive slabs are `slab` floats apart
+__device__ __forceinline__ float sum_partials(const float* p, long slab, int splitk) {
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = 0;
+  for (; k + 3 < splitk; k += 4) {
+    s0 += p[(long)k * slab];
+    s1 += p[(long)(k + 1) * slab];
+    s2 += p[(long)(k + 2) * slab];
+    s3 += p[(long)(k + 3) * slab];
+  }
+  for (; k < splitk; ++k) s0 += p[(long)k * slab];
+  return (s0 + s1) + (s2 + s3);
+}
+
 struct LnBwdArgs {
   const float* dh0;     // [rows][ld0] gradient w.r.t. tanh output (source 0)
   const float* dh1;     // optional second source, summed
@@ -172,6 +187,10 @@ struct LnBwdArgs {
   float* dln;           // [rows][F] scratch: gradient w.r.t. the LN output (for dgamma/dbeta)
   int ld0, ld1, ldh;
   int rows, F;
+  // optional: the incoming gradient is given as split-K partials of `nprob` dgrad GEMMs ([nprob*splitk][rows][ldp],
+  // gemm.hip layout) whose results are added (dh0/dh1 are then unused)
+  const float* part;
+  int splitk, nprob, ldp;
 };
 
 __global__ void ln_tanh_bwd_kernel(LnBwdArgs a) {
@@ -186,8 +205,16 @@ __global__ void ln_tanh_bwd_kernel(LnBwdArgs a) {
     dxh[q] = 0.f;
     xh[q] = 0.f;
     if (f < a.F) {
-      float d = a.dh0[(long)row * a.ld0 + f];
-      if (a.dh1) d += a.dh1[(long)row * a.ld1 + f];
+      float d;
+      if (a.part) {
+        const long slab = (long)a.rows * a.ldp;
+        const float* p = a.part + (long)row * a.ldp + f;
+        d = sum_partials(p, slab, a.splitk);
+        if (a.nprob > 1) d += sum_partials(p + (long)a.splitk * slab, slab, a.splitk);
+      } else {
+        d = a.dh0[(long)row * a.ld0 + f];
+        if (a.dh1) d += a.dh1[(long)row * a.ld1 + f];
+      }
       const float hv = a.h[(long)row * a.ldh + f];
       const float dl = d * (1.f - hv * hv);
       a.dln[(long)row * a.F + f] = dl;
@@ -621,6 +648,12 @@ struct PolOutArgs {
   long lda_out;
   int rows, H, A, srow0, use_clip;
   float std, clip;
+  // optional second sampling job for rows [0, srow0): its own noise table and outputs (the actor update's action
+  // for the obs rows, drqv2.py:210-211, drawn from the same policy output)
+  const float* noise0;
+  float* mu_out0;
+  float* a_out0;
+  long lda_out0;
 };
 
 __global__ void policy_out_kernel(PolOutArgs a) {
@@ -667,14 +700,19 @@ __global__ void policy_out_kernel(PolOutArgs a) {
   }
   if (lane >= a.A) return;
   a.p3[(long)row * a.A + lane] = mine;
-  if (a.noise && row >= a.srow0) {
-    const long r = row - a.srow0;
+  const bool hi_job = a.noise && row >= a.srow0, lo_job = a.noise0 && row < a.srow0;
+  if (hi_job || lo_job) {
+    const long r = hi_job ? row - a.srow0 : row;
+    const float* nz = hi_job ? a.noise : a.noise0;
+    float* mo = hi_job ? a.mu_out : a.mu_out0;
+    float* ao = hi_job ? a.a_out : a.a_out0;
+    const long ld = hi_job ? a.lda_out : a.lda_out0;
     const float mu = tanhf(mine);
-    float eps = a.noise[r * a.A + lane] * a.std;
+    float eps = nz[r * a.A + lane] * a.std;
     if (a.use_clip) eps = fminf(fmaxf(eps, -a.clip), a.clip);
     const float lo = (float)(-1.0 + 1e-6), hi = (float)(1.0 - 1e-6);
-    if (a.mu_out) a.mu_out[r * a.A + lane] = mu;
-    a.a_out[r * a.lda_out + lane] = fminf(fmaxf(mu + eps, lo), hi);
+    if (mo) mo[r * a.A + lane] = mu;
+    ao[r * ld + lane] = fminf(fmaxf(mu + eps, lo), hi);
   }
 }
 
@@ -690,6 +728,8 @@ struct PolBwdArgs {
   float* dw;            // [A][H]
   float* db;            // [A]
   int B, H, A;
+  const float* part;    // optional: da1/da2 as split-K partials [2*splitk][B][A] of the two dgrad GEMMs
+  int splitk;
 };
 
 constexpr int kPolMaxA = 32;
@@ -707,7 +747,16 @@ __global__ __launch_bounds__(1024) void policy_out_bwd_kernel(PolBwdArgs a) {
   for (int i = threadIdx.x; i < a.B * a.A; i += 1024) {
     const int m = i / a.A, j = i - m * a.A;
     const float mv = a.mu[i];
-    dpre[i] = (a.da1[(long)m * a.ld + a.col0 + j] + a.da2[(long)m * a.ld + a.col0 + j]) * (1.f - mv * mv);
+    float d1, d2;
+    if (a.part) {
+      const long slab = (long)a.B * a.A;
+      d1 = sum_partials(a.part + i, slab, a.splitk);
+      d2 = sum_partials(a.part + (long)a.splitk * slab + i, slab, a.splitk);
+    } else {
+      d1 = a.da1[(long)m * a.ld + a.col0 + j];
+      d2 = a.da2[(long)m * a.ld + a.col0 + j];
+    }
+    dpre[i] = (d1 + d2) * (1.f - mv * mv);
   }
   float wn[AMAX], acc[AMAX];
 #pragma unroll
@@ -792,6 +841,10 @@ int drq_ln_tanh_fwd_multi_part(int n, const float* const* z, int ldz, const floa
                                const float* const* beta, float* const* out, const int* ldo, float* const* xhat,
                                float* const* rstd, int rows, int F, const float* const* tail, const int* tail_ld,
                                int tail_n, const float* part, const float* const* bias, int splitk, hipStream_t st);
+int drq_ln_tanh_bwd_part(const float* dh0, int ld0, const float* dh1, int ld1, const float* h, int ldh,
+                         const float* xhat, const float* rstd, const float* gamma, float* dz, float* dln,
+                         float* dgamma, float* dbeta, int rows, int F, const float* part, int splitk, int nprob,
+                         int ldp, hipStream_t st);
 
 int drq_aug_fwd(const uint8_t* obs, const float* shift_xy, const float* base_grid, float* out, int n, int c,
                 int hw, int pad, int fuse_norm, hipStream_t st) {
@@ -842,9 +895,20 @@ int drq_ln_tanh_fwd2(const float* z0, const float* z1, int ldz, const float* gam
 int drq_ln_tanh_bwd(const float* dh0, int ld0, const float* dh1, int ld1, const float* h, int ldh,
                     const float* xhat, const float* rstd, const float* gamma, float* dz, float* dln,
                     float* dgamma, float* dbeta, int rows, int F, hipStream_t st) {
-  if (!dh0 || !h || !xhat || !rstd || !gamma || !dz || !dln || !dgamma || !dbeta || rows <= 0 || F <= 0 || F > 256)
+  return drq_ln_tanh_bwd_part(dh0, ld0, dh1, ld1, h, ldh, xhat, rstd, gamma, dz, dln, dgamma, dbeta, rows, F, nullptr, 0,
+                              0, 0, st);
+}
+
+// internal (step.hip): the incoming gradient may be the split-K partials of 1 or 2 dgrad GEMMs (see LnBwdArgs)
+int drq_ln_tanh_bwd_part(const float* dh0, int ld0, const float* dh1, int ld1, const float* h, int ldh,
+                         const float* xhat, const float* rstd, const float* gamma, float* dz, float* dln,
+                         float* dgamma, float* dbeta, int rows, int F, const float* part, int splitk, int nprob,
+                         int ldp, hipStream_t st) {
+  if ((!dh0 && !part) || !h || !xhat || !rstd || !gamma || !dz || !dln || !dgamma || !dbeta || rows <= 0 || F <= 0 ||
+      F > 256)
     return DRQ_EARG;
-  LnBwdArgs a{dh0, dh1, h, xhat, rstd, gamma, dz, dln, ld0, ld1, ldh, rows, F};
+  if (part && (splitk < 1 || nprob < 1 || nprob > 2 || ldp < F)) return DRQ_EARG;
+  LnBwdArgs a{dh0, dh1, h, xhat, rstd, gamma, dz, dln, ld0, ld1, ldh, rows, F, part, splitk, nprob, ldp};
   hipLaunchKernelGGL(ln_tanh_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, a);
   DRQ_LAUNCH_CHECK();
   hipLaunchKernelGGL(ln_param_grad_kernel, dim3(F), dim3(256), 0, st, (const float*)dln, xhat, dgamma, dbeta, rows, F);
@@ -951,22 +1015,28 @@ int drq_trunc_normal_sample(const float* pre_tanh, const float* noise, float std
 // internal (step.hip): policy output layer forward (+ optional action sampling) and backward, see the kernels
 int drq_policy_out_fwd(const float* h2, const float* w, const float* b, float* p3, int rows, int H, int A,
                        const float* noise, float std, float clip, int use_clip, int srow0, float* mu_out,
-                       float* a_out, long lda_out, hipStream_t st) {
+                       float* a_out, long lda_out, const float* noise0, float* mu_out0, float* a_out0, long lda_out0,
+                       hipStream_t st) {
   if (!h2 || !w || !b || !p3 || rows <= 0 || H <= 0 || A <= 0 || A > 64) return DRQ_EARG;
   if (noise && (!a_out || srow0 < 0 || srow0 > rows)) return DRQ_EARG;
-  PolOutArgs a{h2, w, b, p3, noise, mu_out, a_out, lda_out, rows, H, A, srow0, use_clip, std, clip};
+  if (noise0 && (!a_out0 || !noise)) return DRQ_EARG;
+  PolOutArgs a{h2, w, b, p3, noise, mu_out, a_out, lda_out, rows, H, A, srow0, use_clip, std, clip,
+               noise0, mu_out0, a_out0, lda_out0};
   hipLaunchKernelGGL(policy_out_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, a);
   DRQ_LAUNCH_CHECK();
   return DRQ_OK;
 }
 
 int drq_policy_out_bwd(const float* da1, const float* da2, long ld, int col0, const float* mu, const float* p2,
-                       const float* w, float* dp2, float* dw, float* db, int B, int H, int A, hipStream_t st) {
-  if (!da1 || !da2 || !mu || !p2 || !w || !dp2 || !dw || !db || B <= 0 || H <= 0 || A <= 0 || A > kPolMaxA)
+                       const float* w, float* dp2, float* dw, float* db, int B, int H, int A, const float* part,
+                       int splitk, hipStream_t st) {
+  if (((!da1 || !da2) && !part) || !mu || !p2 || !w || !dp2 || !dw || !db || B <= 0 || H <= 0 || A <= 0 ||
+      A > kPolMaxA)
     return DRQ_EARG;
+  if (part && splitk < 1) return DRQ_EARG;
   const size_t lds = ((size_t)B * A + 16 * 64) * sizeof(float);
   if (lds > 60 * 1024) return DRQ_EARG;
-  PolBwdArgs a{da1, da2, ld, col0, mu, p2, w, dp2, dw, db, B, H, A};
+  PolBwdArgs a{da1, da2, ld, col0, mu, p2, w, dp2, dw, db, B, H, A, part, splitk};
   if (A <= 8) hipLaunchKernelGGL(policy_out_bwd_kernel<8>, dim3((H + 63) / 64), dim3(1024), lds, st, a);
   else if (A <= 16) hipLaunchKernelGGL(policy_out_bwd_kernel<16>, dim3((H + 63) / 64), dim3(1024), lds, st, a);
   else hipLaunchKernelGGL(policy_out_bwd_kernel<32>, dim3((H + 63) / 64), dim3(1024), lds, st, a);

@@ -17,10 +17,15 @@ extern "C" int drq_ln_tanh_fwd_multi_part(int n, const float* const* z, int ldz,
 // elementwise.hip (internal)
 extern "C" int drq_policy_out_fwd(const float* h2, const float* w, const float* b, float* p3, int rows, int H, int A,
                                   const float* noise, float std, float clip, int use_clip, int srow0, float* mu_out,
-                                  float* a_out, long lda_out, hipStream_t st);
+                                  float* a_out, long lda_out, const float* noise0, float* mu_out0, float* a_out0,
+                                  long lda_out0, hipStream_t st);
 extern "C" int drq_policy_out_bwd(const float* da1, const float* da2, long ld, int col0, const float* mu,
                                   const float* p2, const float* w, float* dp2, float* dw, float* db, int B, int H,
-                                  int A, hipStream_t st);
+                                  int A, const float* part, int splitk, hipStream_t st);
+extern "C" int drq_ln_tanh_bwd_part(const float* dh0, int ld0, const float* dh1, int ld1, const float* h, int ldh,
+                                    const float* xhat, const float* rstd, const float* gamma, float* dz, float* dln,
+                                    float* dgamma, float* dbeta, int rows, int F, const float* part, int splitk,
+                                    int nprob, int ldp, hipStream_t st);
 extern "C" int drq_ln_tanh_fwd_multi_ex(int n, const float* const* z, int ldz, const float* const* gamma,
                                         const float* const* beta, float* const* out, const int* ldo,
                                         float* const* xhat, float* const* rstd, int rows, int F,
@@ -236,8 +241,12 @@ int encoder_forward(const Ctx& c, const float* x, int nb, float* a1, float* a2, 
 // policy MLP (drqv2.py:77-81) on `rows` rows of h -> pre-tanh output p3
 // sample_from >= 0: rows [sample_from, rows) also get their action sampled with `noise` into a_out (the output-layer
 // kernel does both); needs A <= 64, else the output layer is a GEMM and the caller samples separately (returns 1)
+// noise0 (with sample_from > 0): rows [0, sample_from) are sampled too, with their own noise, into (mu_out0, a_out0);
+// returns 0, or 2 when that second job could not ride along (the caller then samples those rows itself)
 int policy_forward(const Ctx& c, const float* h, int rows, float* p1, float* p2, float* p3, int sample_from = -1,
-                   const float* noise = nullptr, float* a_out = nullptr, long lda_out = 0) {
+                   const float* noise = nullptr, float* a_out = nullptr, long lda_out = 0,
+                   const float* noise0 = nullptr, float* mu_out0 = nullptr, float* a_out0 = nullptr, long lda_out0 = 0,
+                   bool* did_rows0 = nullptr) {
   const DrqStep* s = c.s;
   const HeadOff& a = c.P.actor;
   const int H = s->H, F = s->F, A = s->A;
@@ -249,7 +258,9 @@ int policy_forward(const Ctx& c, const float* h, int rows, float* p1, float* p2,
   CK(c.fwd(1, x1, H, w1, b1, y1, H, rows, H, H, 1));
   if (A <= 64) {
     CK(drq_policy_out_fwd(p2, w2[0], b2[0], p3, rows, H, A, sample_from >= 0 ? noise : nullptr, s->std, s->clip, 1,
-                          sample_from >= 0 ? sample_from : 0, nullptr, a_out, lda_out, c.st));
+                          sample_from >= 0 ? sample_from : 0, nullptr, a_out, lda_out,
+                          sample_from > 0 ? noise0 : nullptr, mu_out0, a_out0, lda_out0, c.st));
+    if (did_rows0) *did_rows0 = sample_from > 0 && noise0 != nullptr;
     return 0;
   }
   CK(c.fwd(1, x2, H, w2, b2, y2, A, rows, A, H, 0));
@@ -343,7 +354,14 @@ int phase_critic_heads(const Ctx& c) {
   }
   // policy MLP once on the 2B stacked rows
   // ... and, in the output-layer kernel, a' ~ TruncN(actor(next)) for the target (:180-183)
-  CK(policy_forward(c, hrows, 2 * B, c.ws(W_P1), c.ws(W_P2), c.ws(W_P3), B, s->noise_critic, c.ws(W_HA_T) + F, FA));
+  // ... and the actor update's own draw for the obs rows (:210-211; same policy output, the actor's weights do
+  // not change in between): mu and the action columns of the second critic input are ready for phase 6
+  bool did0 = false;
+  CK(policy_forward(c, hrows, 2 * B, c.ws(W_P1), c.ws(W_P2), c.ws(W_P3), B, s->noise_critic, c.ws(W_HA_T) + F, FA,
+                    s->noise_actor, c.ws(W_MU_O), c.ws(W_HA_C2) + F, FA, &did0));
+  if (!did0)
+    CK(drq_trunc_normal_sample(c.ws(W_P3), s->noise_actor, s->std, s->clip, 1, c.ws(W_MU_O), c.ws(W_HA_C2) + F, FA, B,
+                               A, st));
 
   // y = r + d*min Q_target(next, a')   (:184-186);  critic(obs, action) (:188)
   {
@@ -359,6 +377,7 @@ int phase_critic_heads(const Ctx& c) {
                 c.ws(W_DQ) + B, s->sums, B, invB, st));
 
   // ---- backward of the critic loss (:200), both heads per launch
+  int sk_dha = 1;
   {
     float *c1[2] = {c.ws(W_C1), c.ws(W_C1) + BH}, *c2[2] = {c.ws(W_C2), c.ws(W_C2) + BH};
     float *dc1[2] = {c.ws(W_DC1), c.ws(W_DC1) + BH}, *dc2[2] = {c.ws(W_DC2), c.ws(W_DC2) + BH};
@@ -379,11 +398,14 @@ int phase_critic_heads(const Ctx& c) {
     CK(c.dgrad(2, dc2c, H, w1, H, dc1, H, B, H, H, c1c, H));
     // layer 1 (input = [h, action], shared by both heads)
     CK(c.wgrad(2, dc1c, H, hac, FA, gw0, gb0, B, H, FA));
-    CK(c.dgrad(2, dc1c, H, w0, FA, dha, FA, B, FA, H, nullptr, 0));
+    // the split-K partials of this dgrad stay in the workspace: the LayerNorm backward sums them (both heads)
+    CK(drq_gemm_batched_partial(2, dc1c, H, 1, w0, FA, 0, dha, FA, B, FA, H, nullptr, c.gemm_ws(), c.gemm_ws_bytes(),
+                                &sk_dha, st));
   }
   // trunk: LayerNorm+tanh backward, then Linear(R -> F)
-  CK(drq_ln_tanh_bwd(c.ws(W_DHA), FA, c.ws(W_DHA) + (long)B * FA, FA, c.ws(W_HA_C), FA, c.ws(W_XHAT_C),
-                     c.ws(W_RSTD_C), c.p(cr.ln_g), c.ws(W_DZ_C), c.ws(W_DLN), c.g(cr.ln_g), c.g(cr.ln_b), B, F, st));
+  CK(drq_ln_tanh_bwd_part(c.ws(W_DHA), FA, c.ws(W_DHA) + (long)B * FA, FA, c.ws(W_HA_C), FA, c.ws(W_XHAT_C),
+                          c.ws(W_RSTD_C), c.p(cr.ln_g), c.ws(W_DZ_C), c.ws(W_DLN), c.g(cr.ln_g), c.g(cr.ln_b), B, F,
+                          sk_dha > 1 ? c.gemm_ws() : nullptr, sk_dha, 2, FA, st));
   {
     const float *dz[1] = {c.ws(W_DZ_C)}, *x[1] = {feat_obs}, *w[1] = {c.p(cr.trunk_w)}, *mk[1] = {feat_obs};
     float *gw[1] = {c.g(cr.trunk_w)}, *gb[1] = {c.g(cr.trunk_b)}, *dy4[1] = {c.ws(W_DY4)};
@@ -463,9 +485,7 @@ int phase_actor_forward(const Ctx& c) {
   CK(drq_adam_flat(c.p(P.seg[2]), c.g(P.seg[2]), s->adam_m + P.seg[2], s->adam_v + P.seg[2], P.seg[3] - P.seg[2],
                    s->lr, s->step_critic, s->gscale, c.p(P.seg[6]), s->tau, st));
 
-  // a ~ TruncN(actor(obs.detach())) (:210-211): the policy MLP output for the obs rows was computed in phase 0
-  CK(drq_trunc_normal_sample(c.ws(W_P3), s->noise_actor, s->std, s->clip, 1, c.ws(W_MU_O), c.ws(W_HA_C2) + F, FA, B,
-                             A, st));
+  // a ~ TruncN(actor(obs.detach())) (:210-211) was drawn in phase 4 together with the policy output
   // updated critic on (obs, a) (:213)
   {
     const float *x[1] = {feat_obs}, *w[1] = {c.p(cr.trunk_w)}, *b[1] = {c.p(cr.trunk_b)};
@@ -501,6 +521,9 @@ int phase_actor_backward(const Ctx& c) {
   const HeadOff &cr = P.critic, &ac = P.actor;
   const long BH = (long)B * H;
 
+  // output layer backward in one kernel (dpre, dW3, db3, dp2) when dpre fits its LDS
+  const bool fused_head = A <= 32 && ((size_t)B * A + 1024) * 4 <= 60 * 1024;
+  int sk_da = 1;
   // backward through the critic to the action only (critic weight grads are never used: SURVEY A7(iii))
   {
     const float *dq[2] = {c.ws(W_DQ), c.ws(W_DQ) + B};
@@ -512,13 +535,19 @@ int phase_actor_backward(const Ctx& c) {
     float* da[2] = {c.ws(W_DA), c.ws(W_DA) + (long)B * A};
     CK(drq_qout_bwd(2, dq, t2, w2, dc2, nullptr, nullptr, B, H, st));
     CK(c.dgrad(2, dc2c, H, w1, H, dc1, H, B, H, H, t1, H));
-    CK(c.dgrad(2, dc1c, H, w0a, FA, da, A, B, A, H, nullptr, 0));     // action columns of layer 1 only
+    // action columns of layer 1 only; with the fused output-layer backward the split-K partials stay in the
+    // workspace and that kernel sums them
+    if (fused_head)
+      CK(drq_gemm_batched_partial(2, dc1c, H, 1, w0a, FA, 0, da, A, B, A, H, nullptr, c.gemm_ws(), c.gemm_ws_bytes(),
+                                  &sk_da, st));
+    else
+      CK(c.dgrad(2, dc1c, H, w0a, FA, da, A, B, A, H, nullptr, 0));
   }
-  // output layer backward in one kernel (dpre, dW3, db3, dp2) when dpre fits its LDS
-  const bool fused_head = A <= 32 && ((size_t)B * A + 1024) * 4 <= 60 * 1024;
+
   if (!fused_head) CK(drq_actor_dmu(c.ws(W_DA), c.ws(W_DA) + (long)B * A, A, 0, c.ws(W_MU_O), c.ws(W_DPRE), B, A, st));
 
   // policy MLP backward (rows [0,B) of the stacked activations are the obs rows)
+  int sk_dh = 1;
   {
     const float *dpre[1] = {c.ws(W_DPRE)}, *p1[1] = {c.ws(W_P1)}, *p2[1] = {c.ws(W_P2)}, *h[1] = {c.ws(W_HROWS)};
     float *dp1[1] = {c.ws(W_DP1)}, *dp2[1] = {c.ws(W_DP2)}, *dh[1] = {c.ws(W_DH_A)};
@@ -528,7 +557,7 @@ int phase_actor_backward(const Ctx& c) {
     float *gb0[1] = {c.g(ac.b[0][0])}, *gb1[1] = {c.g(ac.b[0][1])}, *gb2[1] = {c.g(ac.b[0][2])};
     if (fused_head) {
       CK(drq_policy_out_bwd(c.ws(W_DA), c.ws(W_DA) + (long)B * A, A, 0, c.ws(W_MU_O), p2[0], w2[0], dp2[0], gw2[0],
-                            gb2[0], B, H, A, st));
+                            gb2[0], B, H, A, sk_da > 1 ? c.gemm_ws() : nullptr, sk_da, st));
     } else {
       CK(c.wgrad(1, dpre, A, p2, H, gw2, gb2, B, A, H));
       CK(c.dgrad(1, dpre, A, w2, H, dp2, H, B, H, A, p2, H));
@@ -536,10 +565,12 @@ int phase_actor_backward(const Ctx& c) {
     CK(c.wgrad(1, dp2c, H, p1, H, gw1, gb1, B, H, H));
     CK(c.dgrad(1, dp2c, H, w1, H, dp1, H, B, H, H, p1, H));
     CK(c.wgrad(1, dp1c, H, h, F, gw0, gb0, B, H, F));
-    CK(c.dgrad(1, dp1c, H, w0, F, dh, F, B, F, H, nullptr, 0));
+    CK(drq_gemm_batched_partial(1, dp1c, H, 1, w0, F, 0, dh, F, B, F, H, nullptr, c.gemm_ws(), c.gemm_ws_bytes(), &sk_dh,
+                                st));
   }
-  CK(drq_ln_tanh_bwd(c.ws(W_DH_A), F, nullptr, 0, c.ws(W_HROWS), F, c.ws(W_XHAT_A), c.ws(W_RSTD_A), c.p(ac.ln_g),
-                     c.ws(W_DZ_A), c.ws(W_DLN), c.g(ac.ln_g), c.g(ac.ln_b), B, F, st));
+  CK(drq_ln_tanh_bwd_part(c.ws(W_DH_A), F, nullptr, 0, c.ws(W_HROWS), F, c.ws(W_XHAT_A), c.ws(W_RSTD_A), c.p(ac.ln_g),
+                          c.ws(W_DZ_A), c.ws(W_DLN), c.g(ac.ln_g), c.g(ac.ln_b), B, F,
+                          sk_dh > 1 ? c.gemm_ws() : nullptr, sk_dh, 1, F, st));
   {
     const float *dz[1] = {c.ws(W_DZ_A)}, *x[1] = {feat_obs};
     float *gw[1] = {c.g(ac.trunk_w)}, *gb[1] = {c.g(ac.trunk_b)};
