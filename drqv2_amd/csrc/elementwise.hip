@@ -535,36 +535,63 @@ struct QOutBwdArgs {
   float* dw[8];         // [H] or null
   float* db[8];         // [1] or null
   int B, H;
+  // optional fused TD loss (drqv2.py:185-189, two heads: z = 0, 1): dq is not given but computed per row from the
+  // Q values; workgroup (0, 0) also leaves sums[0..4] like td_loss_kernel
+  int td;
+  const float *tq1, *tq2, *q1, *q2, *reward, *discount;
+  float invB;
+  float* sums;
 };
 
+// Workgroup = 64 columns x 16 row groups (1024 threads).  The per-row scalars dq[B] go to LDS once; the only global
+// stream of the row loop is h, 16 rows of it in flight per thread.
 __global__ __launch_bounds__(1024) void qout_bwd_kernel(QOutBwdArgs a) {
-  __shared__ float s[16][64];
-  __shared__ float sb[16];
+  extern __shared__ float dql[];            // [B] then 16 x 64 + 16 floats of reduction scratch
+  float* s = dql + a.B;
+  float* sb = s + (a.td ? 5 * 1024 : 16 * 64);
   const int z = blockIdx.y;
   const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + c;
-  const float* dq = a.dq[z];
+  const bool nok = n < a.H;
+  const int nc = nok ? n : a.H - 1;
   const float* h = a.h[z];
   float* dh = a.dh[z];
-  const float wn = n < a.H ? a.w[z][n] : 0.f;
+  const float wn = a.w[z][nc];
+  if (a.td) {
+    const float* qz = z == 0 ? a.q1 : a.q2;
+    for (int m = threadIdx.x; m < a.B; m += 1024) {
+      const float y = a.reward[m] + a.discount[m] * fminf(a.tq1[m], a.tq2[m]);
+      dql[m] = 2.f * (qz[m] - y) * a.invB;
+    }
+  } else {
+    const float* dq = a.dq[z];
+    for (int m = threadIdx.x; m < a.B; m += 1024) dql[m] = dq[m];
+  }
+  __syncthreads();
   float acc = 0.f, bacc = 0.f;
-  for (int m = rg; m < a.B; m += 16) {
-    const float d = dq[m];
-    bacc += d;
-    if (n < a.H) {
-      const float hv = h[(long)m * a.H + n];
-      dh[(long)m * a.H + n] = hv > 0.f ? d * wn : 0.f;
-      acc = __fmaf_rn(d, hv, acc);
+  for (int m0 = rg; m0 < a.B; m0 += 16 * 16) {
+    float hv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) hv[u] = h[(long)min(m0 + 16 * u, a.B - 1) * a.H + nc];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int m = m0 + 16 * u;
+      if (m < a.B) {
+        const float d = dql[m];
+        bacc += d;
+        if (nok) dh[(long)m * a.H + n] = hv[u] > 0.f ? d * wn : 0.f;
+        acc = __fmaf_rn(d, hv[u], acc);
+      }
     }
   }
-  s[rg][c] = acc;
+  s[rg * 64 + c] = acc;
   if (c == 0) sb[rg] = bacc;
   __syncthreads();
   if (rg == 0) {
-    if (a.dw[z] && n < a.H) {
+    if (a.dw[z] && nok) {
       float t = 0.f;
 #pragma unroll
-      for (int g2 = 0; g2 < 16; ++g2) t += s[g2][c];
+      for (int g2 = 0; g2 < 16; ++g2) t += s[g2 * 64 + c];
       a.dw[z][n] = t;
     }
     if (a.db[z] && blockIdx.x == 0 && c == 0) {
@@ -573,6 +600,29 @@ __global__ __launch_bounds__(1024) void qout_bwd_kernel(QOutBwdArgs a) {
       for (int g2 = 0; g2 < 16; ++g2) t += sb[g2];
       a.db[z][0] = t;
     }
+  }
+  // metric sums of the TD loss: workgroup (0, 0), per-thread partials over rows tid, tid+1024, ... then a fixed tree
+  if (a.td && blockIdx.x == 0 && z == 0) {
+    __syncthreads();
+    float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int m = threadIdx.x; m < a.B; m += 1024) {
+      const float r = a.reward[m];
+      const float y = r + a.discount[m] * fminf(a.tq1[m], a.tq2[m]);
+      const float e1 = a.q1[m] - y, e2 = a.q2[m] - y;
+      v[0] += r; v[1] += y; v[2] += a.q1[m]; v[3] += a.q2[m]; v[4] += e1 * e1 + e2 * e2;
+    }
+    // one tree for the five sums (scratch: 5 x 1024 floats behind dq)
+#pragma unroll
+    for (int q = 0; q < 5; ++q) s[q * 1024 + threadIdx.x] = v[q];
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) s[q * 1024 + threadIdx.x] += s[q * 1024 + threadIdx.x + o];
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x < 5) a.sums[threadIdx.x] = s[threadIdx.x * 1024];
   }
 }
 
@@ -943,7 +993,34 @@ int drq_qout_bwd(int nz, const float* const* dq, const float* const* h, const fl
     a.db[z] = db ? db[z] : nullptr;
   }
   a.B = B; a.H = H;
-  hipLaunchKernelGGL(qout_bwd_kernel, dim3((H + 63) / 64, nz), dim3(1024), 0, st, a);
+  const size_t lds = ((size_t)B + 16 * 64 + 16) * sizeof(float);
+  if (lds > 60 * 1024) return DRQ_EARG;
+  hipLaunchKernelGGL(qout_bwd_kernel, dim3((H + 63) / 64, nz), dim3(1024), lds, st, a);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
+// internal (step.hip): the twin-Q output layer backward with the TD loss (drq_td_mse) computed inside it:
+// dq1/dq2 never exist in memory, sums[0..4] are written by the same launch
+int drq_qout_bwd_td(const float* tq1, const float* tq2, const float* q1, const float* q2, const float* reward,
+                    const float* discount, float inv_global_B, float* sums, const float* const* h,
+                    const float* const* w, float* const* dh, float* const* dw, float* const* db, int B, int H,
+                    hipStream_t st) {
+  if (!tq1 || !tq2 || !q1 || !q2 || !reward || !discount || !sums || !h || !w || !dh || B <= 0 || H <= 0)
+    return DRQ_EARG;
+  QOutBwdArgs a{};
+  for (int z = 0; z < 2; ++z) {
+    if (!h[z] || !w[z] || !dh[z]) return DRQ_EARG;
+    a.h[z] = h[z]; a.w[z] = w[z]; a.dh[z] = dh[z];
+    a.dw[z] = dw ? dw[z] : nullptr;
+    a.db[z] = db ? db[z] : nullptr;
+  }
+  a.B = B; a.H = H;
+  a.td = 1; a.tq1 = tq1; a.tq2 = tq2; a.q1 = q1; a.q2 = q2; a.reward = reward; a.discount = discount;
+  a.invB = inv_global_B; a.sums = sums;
+  const size_t lds = ((size_t)B + 5 * 1024 + 16) * sizeof(float);      // the sums tree of workgroup (0,0) needs 5 x 1024
+  if (lds > 60 * 1024) return DRQ_EARG;
+  hipLaunchKernelGGL(qout_bwd_kernel, dim3((H + 63) / 64, 2), dim3(1024), lds, st, a);
   DRQ_LAUNCH_CHECK();
   return DRQ_OK;
 }

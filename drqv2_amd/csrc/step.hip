@@ -15,6 +15,10 @@ extern "C" int drq_ln_tanh_fwd_multi_part(int n, const float* const* z, int ldz,
                                           const float* const* tail, const int* tail_ld, int tail_n, const float* part,
                                           const float* const* bias, int splitk, hipStream_t st);
 // elementwise.hip (internal)
+extern "C" int drq_qout_bwd_td(const float* tq1, const float* tq2, const float* q1, const float* q2, const float* reward,
+                               const float* discount, float inv_global_B, float* sums, const float* const* h,
+                               const float* const* w, float* const* dh, float* const* dw, float* const* db, int B,
+                               int H, hipStream_t st);
 extern "C" int drq_policy_out_fwd(const float* h2, const float* w, const float* b, float* p3, int rows, int H, int A,
                                   const float* noise, float std, float clip, int use_clip, int srow0, float* mu_out,
                                   float* a_out, long lda_out, const float* noise0, float* mu_out0, float* a_out0,
@@ -373,8 +377,6 @@ int phase_critic_heads(const Ctx& c) {
     CK(q_forward(c, 2, nets, ha, h1, h2, q));
   }
   const float invB = 1.0f / (float)s->global_B;
-  CK(drq_td_mse(c.ws(W_TQ), c.ws(W_TQ) + B, c.ws(W_Q), c.ws(W_Q) + B, s->reward, s->discount, c.ws(W_DQ),
-                c.ws(W_DQ) + B, s->sums, B, invB, st));
 
   // ---- backward of the critic loss (:200), both heads per launch
   int sk_dha = 1;
@@ -391,8 +393,16 @@ int phase_critic_heads(const Ctx& c) {
           *gw2[2] = {c.g(cr.w[0][2]), c.g(cr.w[1][2])};
     float *gb0[2] = {c.g(cr.b[0][0]), c.g(cr.b[1][0])}, *gb1[2] = {c.g(cr.b[0][1]), c.g(cr.b[1][1])},
           *gb2[2] = {c.g(cr.b[0][2]), c.g(cr.b[1][2])};
-    // layer 3 (hidden -> 1): dgrad + wgrad + bias grad in one pass
-    CK(drq_qout_bwd(2, dq, c2c, w2, dc2, gw2, gb2, B, H, st));
+    // TD target + twin MSE (:185-189) and layer 3 (hidden -> 1) backward in one pass: dq never leaves the chip,
+    // sums[0..4] come from the same launch
+    if (((size_t)B + 5 * 1024 + 16) * 4 <= 60 * 1024) {
+      CK(drq_qout_bwd_td(c.ws(W_TQ), c.ws(W_TQ) + B, c.ws(W_Q), c.ws(W_Q) + B, s->reward, s->discount, invB, s->sums,
+                         c2c, w2, dc2, gw2, gb2, B, H, st));
+    } else {
+      CK(drq_td_mse(c.ws(W_TQ), c.ws(W_TQ) + B, c.ws(W_Q), c.ws(W_Q) + B, s->reward, s->discount, c.ws(W_DQ),
+                    c.ws(W_DQ) + B, s->sums, B, invB, st));
+      CK(drq_qout_bwd(2, dq, c2c, w2, dc2, gw2, gb2, B, H, st));
+    }
     // layer 2
     CK(c.wgrad(2, dc2c, H, c1c, H, gw1, gb1, B, H, H));
     CK(c.dgrad(2, dc2c, H, w1, H, dc1, H, B, H, H, c1c, H));
