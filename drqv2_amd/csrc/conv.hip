@@ -858,7 +858,13 @@ __global__ __launch_bounds__(1024) void conv3x3_wgrad_reduce_multi_kernel(Reduce
   const int i = blockIdx.x * 64 + e;
   if (blockIdx.x * 64 >= PART) return;      // uniform per workgroup
   float s = 0.f;
-  for (int k = grp; k < J.nblocks; k += 16) s += J.part[(long)k * PART + i];
+  for (int k0 = grp; k0 < J.nblocks; k0 += 16 * 16) {     // 16 records in flight per thread, added in order
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = J.part[(long)min(k0 + 16 * u, J.nblocks - 1) * PART + i];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += (k0 + 16 * u < J.nblocks) ? v[u] : 0.f;
+  }
   sm[grp][e] = s;
   __syncthreads();
   if (grp != 0) return;

@@ -517,12 +517,28 @@ __global__ void qout_fwd_kernel(QOutArgs a) {
   const float* h = a.h[z] + (long)row * a.H;
   const float* w = a.w[z];
   float s0 = 0.f, s1 = 0.f;
-  int i = lane;
-  for (; i + 64 < a.H; i += 128) {
-    s0 = __fmaf_rn(h[i], w[i], s0);
-    s1 = __fmaf_rn(h[i + 64], w[i + 64], s1);
+  if (a.H <= 1024) {
+    // all (up to) 32 loads of the row in flight at once; same summation order as the loop below
+    float hv[16], wv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int i = min(lane + 64 * q, a.H - 1);
+      hv[q] = h[i];
+      wv[q] = (lane + 64 * q < a.H) ? w[i] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; q += 2) {
+      s0 = __fmaf_rn(hv[q], wv[q], s0);
+      s1 = __fmaf_rn(hv[q + 1], wv[q + 1], s1);
+    }
+  } else {
+    int i = lane;
+    for (; i + 64 < a.H; i += 128) {
+      s0 = __fmaf_rn(h[i], w[i], s0);
+      s1 = __fmaf_rn(h[i + 64], w[i + 64], s1);
+    }
+    if (i < a.H) s0 = __fmaf_rn(h[i], w[i], s0);
   }
-  if (i < a.H) s0 = __fmaf_rn(h[i], w[i], s0);
   const float s = wave_sum(s0 + s1);
   if (lane == 0) a.q[z][row] = s + a.b[z][0];
 }
