@@ -99,6 +99,27 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// sum of the split-K partial slabs of one GEMM output element, in splitk_reduce_kernel's association
+// (gemm.hip): p points at the element in slab 0, consecutive slabs are `slab` floats apart
+__device__ __forceinline__ float sum_partials(const float* p, long slab, int splitk) {
+  // four interleaved chains (slab k goes to chain k & 3), then a tree: splitk_reduce_kernel's order.  16 slabs are
+  // loaded per batch so that a thread pays one memory round trip per 16 slabs, not one per 4.
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (int k0 = 0; k0 < splitk; k0 += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = p[(long)min(k0 + u, splitk - 1) * slab];
+#pragma unroll
+    for (int u = 0; u < 16; u += 4) {
+      if (k0 + u < splitk) s0 += v[u];
+      if (k0 + u + 1 < splitk) s1 += v[u + 1];
+      if (k0 + u + 2 < splitk) s2 += v[u + 2];
+      if (k0 + u + 3 < splitk) s3 += v[u + 3];
+    }
+  }
+  return (s0 + s1) + (s2 + s3);
+}
+
 __global__ void ln_tanh_fwd_kernel(LnArgs a) {
   const int g = blockIdx.y;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -112,17 +133,8 @@ __global__ void ln_tanh_fwd_kernel(LnArgs a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int f = lane + 64 * q;
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
       if (f < a.F) {
-        int k = 0;
-        for (; k + 3 < a.splitk; k += 4) {
-          s0 += p[(long)k * mn + f];
-          s1 += p[(long)(k + 1) * mn + f];
-          s2 += p[(long)(k + 2) * mn + f];
-          s3 += p[(long)(k + 3) * mn + f];
-        }
-        for (; k < a.splitk; ++k) s0 += p[(long)k * mn + f];
-        v[q] = ((s0 + s1) + (s2 + s3)) + (a.bias[g] ? a.bias[g][f] : 0.f);
+        v[q] = sum_partials(p + f, mn, a.splitk) + (a.bias[g] ? a.bias[g][f] : 0.f);
       } else {
         v[q] = 0.f;
       }
@@ -159,21 +171,6 @@ __global__ void ln_tanh_fwd_kernel(LnArgs a) {
   }
   if (lane == 0 && a.rstd[g]) a.rstd[g][row] = rstd;
   if (a.tail[g] && lane < a.tail_n) a.out[g][(long)row * a.ldo[g] + a.F + lane] = a.tail[g][(long)row * a.tail_ld[g] + lane];
-}
-
-// sum of the split-K partial slabs of one GEMM output element, in splitk_reduce_kernel's association
-// (gemm.hip): p points at the element in slab 0, consecutive slabs are `slab` floats apart
-__device__ __forceinline__ float sum_partials(const float* p, long slab, int splitk) {
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int k = 0;
-  for (; k + 3 < splitk; k += 4) {
-    s0 += p[(long)k * slab];
-    s1 += p[(long)(k + 1) * slab];
-    s2 += p[(long)(k + 2) * slab];
-    s3 += p[(long)(k + 3) * slab];
-  }
-  for (; k < splitk; ++k) s0 += p[(long)k * slab];
-  return (s0 + s1) + (s2 + s3);
 }
 
 struct LnBwdArgs {
