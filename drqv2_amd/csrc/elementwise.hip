@@ -13,10 +13,13 @@ namespace {
 // base[j] + shift*2/S.  One thread per output pixel, looping over channels (coordinates and the
 // four tap weights are per (sample,y,x)).  Arithmetic follows ATen's GridSampler scalar formulas.
 // ------------------------------------------------------------------------------------------------
+// obs1/shift1 (optional): a second set of n frames handled by blockIdx.y == 1, written behind the first n frames of
+// out (the update augments obs and next_obs with independent shifts: one launch for both)
 template <typename T>
 __global__ void aug_kernel(const T* __restrict__ obs, const float* __restrict__ shift,
                            const float* __restrict__ base, float* __restrict__ out, int n, int c, int h,
-                           int pad, int fuse_norm) {
+                           int pad, int fuse_norm, const T* __restrict__ obs1 = nullptr,
+                           const float* __restrict__ shift1 = nullptr) {
   // one rounding per operation, in the order of the CPU restatement (oracle/drq_oracle.py
   // random_shifts_aug): the tap weights are differences of nearly equal numbers, so a fused
   // multiply-add anywhere in the coordinate chain changes them by O(1) relative.
@@ -24,6 +27,11 @@ __global__ void aug_kernel(const T* __restrict__ obs, const float* __restrict__ 
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int hw = h * h;
   if (idx >= (long)n * hw) return;
+  if (blockIdx.y == 1) {
+    obs = obs1;
+    shift = shift1;
+    out += (long)n * c * hw;
+  }
   const int b = (int)(idx / hw);
   const int r = (int)(idx - (long)b * hw);
   const int i = r / h, j = r - i * h;
@@ -915,6 +923,18 @@ int drq_aug_fwd(const uint8_t* obs, const float* shift_xy, const float* base_gri
   const long total = (long)n * hw * hw;
   hipLaunchKernelGGL(aug_kernel<uint8_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, obs, shift_xy,
                      base_grid, out, n, c, hw, pad, fuse_norm);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
+// internal (step.hip): both views of the update in one launch; out = [2n][c][hw][hw], obs rows first
+int drq_aug_fwd_pair(const uint8_t* obs, const float* shift, const uint8_t* obs1, const float* shift1,
+                     const float* base_grid, float* out, int n, int c, int hw, int pad, int fuse_norm, hipStream_t st) {
+  if (!obs || !shift || !obs1 || !shift1 || !base_grid || !out || n <= 0 || c <= 0 || hw <= 0 || pad < 0)
+    return DRQ_EARG;
+  const long total = (long)n * hw * hw;
+  hipLaunchKernelGGL(aug_kernel<uint8_t>, dim3((unsigned)((total + 255) / 256), 2), dim3(256), 0, st, obs, shift,
+                     base_grid, out, n, c, hw, pad, fuse_norm, obs1, shift1);
   DRQ_LAUNCH_CHECK();
   return DRQ_OK;
 }

@@ -15,6 +15,9 @@ extern "C" int drq_ln_tanh_fwd_multi_part(int n, const float* const* z, int ldz,
                                           const float* const* tail, const int* tail_ld, int tail_n, const float* part,
                                           const float* const* bias, int splitk, hipStream_t st);
 // elementwise.hip (internal)
+extern "C" int drq_aug_fwd_pair(const uint8_t* obs, const float* shift, const uint8_t* obs1, const float* shift1,
+                                const float* base_grid, float* out, int n, int c, int hw, int pad, int fuse_norm,
+                                hipStream_t st);
 extern "C" int drq_qout_bwd_td(const float* tq1, const float* tq2, const float* q1, const float* q2, const float* reward,
                                const float* discount, float inv_global_B, float* sums, const float* const* h,
                                const float* const* w, float* const* dh, float* const* dw, float* const* db, int B,
@@ -308,8 +311,7 @@ int phase_encode(const Ctx& c) {
   hipStream_t st = c.st;
   float* aug = c.ws(W_AUG);
   // aug (drqv2.py:241-242) + /255-0.5 (:64); rows [0,B) = obs, [B,2B) = next_obs
-  CK(drq_aug_fwd(s->obs, s->shift_obs, s->base_grid, aug, B, C, 84, 4, 1, st));
-  CK(drq_aug_fwd(s->next_obs, s->shift_next, s->base_grid, aug + (long)B * C * 84 * 84, B, C, 84, 4, 1, st));
+  CK(drq_aug_fwd_pair(s->obs, s->shift_obs, s->next_obs, s->shift_next, s->base_grid, aug, B, C, 84, 4, 1, st));
   // encoder on both views in one pass (:244-246)
   CK(encoder_forward(c, aug, 2 * B, c.ws(W_ACT1), c.ws(W_ACT2), c.ws(W_ACT3), c.ws(W_FEAT), true));
   return 0;
