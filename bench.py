@@ -127,13 +127,17 @@ def main():
         torch.cuda.synchronize()
 
     sync()
+    stamps = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         metrics = agent.update(it, step)
         step += 2
+        stamps.append(time.perf_counter())       # update() returns when its metrics have left the GPU
     agent.flush()          # data parallel: the last update's deferred Adam(actor) belongs to the timed region
     sync()
     dt = time.perf_counter() - t0
+    per = sorted(1e3 * (b - a) for a, b in zip(stamps[:-1], stamps[1:]))
+    pct = (lambda q: per[min(len(per) - 1, int(q * len(per)))]) if per else (lambda q: None)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
