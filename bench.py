@@ -147,6 +147,7 @@ def main():
     out = {
         "metric": "agent updates/sec (batch=256, 9x84x84 obs)", "value": value, "unit": "updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "ms_per_step_p10_p50_p90": [pct(0.1), pct(0.5), pct(0.9)],
         "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic" + (" (batch copied host->device every update)" if args.host_batch else "")
                                 + (" (batches assembled by the device replay)" if args.device_replay else ""),
