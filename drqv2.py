@@ -237,7 +237,45 @@ class DrQV2Agent:
                 "critic": cpu(self.critic.state_dict()), "critic_target": cpu(self.critic_target.state_dict()),
                 "opt": {n: getattr(self, n).export_state() for n in ("encoder_opt", "actor_opt", "critic_opt")}}
 
+    def _load_reference_state(self, st):
+        """`st` is the __dict__ of an agent pickled by the REFERENCE's class (train.py:192-198 pickles the object and
+        the reference defines no __getstate__): nn.Modules, torch.optim.Adam objects, scalar attributes.  With this
+        module on the path pickle resolves `drqv2.DrQV2Agent` to this class and hands that dict over here; the agent
+        is rebuilt on the arenas, weights and Adam moments are copied in."""
+        cpu = lambda m: {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        sds = {n: cpu(st[n]) for n in ("encoder", "actor", "critic", "critic_target")}
+        a = sds["actor"]
+        dev = st.get("device", "cuda")
+        if str(dev).startswith("cuda") and not torch.cuda.is_available():
+            dev = "cpu"
+        kw = dict(obs_shape=(sds["encoder"]["convnet.0.weight"].shape[1], 84, 84),
+                  action_shape=(a["policy.4.weight"].shape[0],), device=dev,
+                  lr=st["actor_opt"].param_groups[0]["lr"], feature_dim=a["trunk.0.weight"].shape[0],
+                  hidden_dim=a["policy.0.weight"].shape[0], critic_target_tau=st["critic_target_tau"],
+                  num_expl_steps=st["num_expl_steps"], update_every_steps=st["update_every_steps"],
+                  stddev_schedule=st["stddev_schedule"], stddev_clip=st["stddev_clip"], use_tb=st["use_tb"])
+        with torch.random.fork_rng(devices=[]):
+            self.__init__(**kw)
+        for n, sd in sds.items():
+            getattr(self, n).load_state_dict(sd)
+        eng = self._engine
+        for net, opt_name in (("enc", "encoder_opt"), ("actor", "actor_opt"), ("critic", "critic_opt")):
+            ref = st[opt_name].state_dict()["state"]          # param index -> {step, exp_avg, exp_avg_sq}
+            mine = getattr(self, opt_name)
+            t = 0
+            for i, off in enumerate(eng.layout[net]):
+                if i not in ref:
+                    continue
+                m, v = ref[i]["exp_avg"], ref[i]["exp_avg_sq"]
+                eng.adam_m[off:off + m.numel()].copy_(m.reshape(-1))
+                eng.adam_v[off:off + v.numel()].copy_(v.reshape(-1))
+                t = max(t, int(ref[i]["step"]))
+            mine.t = t
+        self.train(bool(st.get("training", True)))
+
     def __setstate__(self, st):
+        if "init" not in st:
+            return self._load_reference_state(st)
         kw = dict(st["init"])
         if str(kw["device"]).startswith("cuda") and not torch.cuda.is_available():
             kw["device"] = "cpu"

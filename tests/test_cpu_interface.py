@@ -104,6 +104,46 @@ def test_pickle_roundtrip_cpu():
     assert ag2.use_tb is False and ag2.stddev_schedule == "0.2"
 
 
+def test_reference_format_snapshot_loads():
+    """A snapshot written by the reference (train.py:192-198) is a pickle of ITS agent object: class path
+    `drqv2.DrQV2Agent`, state = the object's __dict__ (modules, torch.optim.Adam objects, scalars).  With this
+    repo's drqv2.py on the path pickle hands that dict to DrQV2Agent.__setstate__; the stand-in below produces
+    exactly such a pickle stream (the reference itself cannot be imported in the test suite)."""
+    import drqv2
+    torch.manual_seed(3)
+    src = drqv2.DrQV2Agent((9, 84, 84), (3,), "cpu", 2e-4, 20, 64, 0.02, 1500, 2, "linear(1.0,0.1,1000)", 0.25, False)
+    mods = {n: getattr(src, n) for n in ("encoder", "actor", "critic", "critic_target")}
+    ref_state = dict(device="cpu", critic_target_tau=0.02, update_every_steps=2, use_tb=False, num_expl_steps=1500,
+                     stddev_schedule="linear(1.0,0.1,1000)", stddev_clip=0.25, training=True, aug=None, **mods)
+    for n, m in (("encoder_opt", src.encoder), ("actor_opt", src.actor), ("critic_opt", src.critic)):
+        ps = [torch.nn.Parameter(p.detach().clone()) for p in m.parameters()]
+        opt = torch.optim.Adam(ps, lr=2e-4)
+        for k in range(3):                                   # three real Adam steps populate exp_avg / exp_avg_sq / step
+            for p in ps:
+                p.grad = torch.randn_like(p) * 0.1
+            opt.step()
+        ref_state[n] = opt
+
+    class RefPickle:                                         # pickles as the reference's object would:
+        def __reduce__(self):                                # new object of class drqv2.DrQV2Agent, then setstate
+            return (object.__new__, (drqv2.DrQV2Agent,), ref_state)
+
+    ag = pickle.loads(pickle.dumps(RefPickle()))
+    assert isinstance(ag, drqv2.DrQV2Agent) and ag.critic_target_tau == 0.02 and ag.stddev_clip == 0.25
+    assert ag.num_expl_steps == 1500 and ag.use_tb is False and ag.actor_opt.lr == 2e-4
+    for n, m in mods.items():
+        for (k, a), (_, b) in zip(m.state_dict().items(), getattr(ag, n).state_dict().items()):
+            assert torch.equal(a.detach().cpu(), b.detach().cpu()), (n, k)
+    eng = ag._engine
+    for net, on in (("enc", "encoder_opt"), ("actor", "actor_opt"), ("critic", "critic_opt")):
+        ref = ref_state[on].state_dict()["state"]
+        assert getattr(ag, on).t == 3
+        for i, off in enumerate(eng.layout[net]):
+            m = ref[i]["exp_avg"].reshape(-1)
+            assert torch.equal(eng.adam_m[off:off + m.numel()].cpu(), m)
+            assert torch.equal(eng.adam_v[off:off + m.numel()].cpu(), ref[i]["exp_avg_sq"].reshape(-1))
+
+
 def test_c_abi_exports_every_declared_symbol():
     """include/drqv2_hip.h <-> libdrqv2_hip.so <-> the ctypes prototype table."""
     from drqv2_amd import _lib
