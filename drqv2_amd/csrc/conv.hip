@@ -966,7 +966,10 @@ int launch_wgrad(const WgradArgs& a0, float* dw, float* db, float* ws, size_t ws
   constexpr int lds1 = (4 * G::WAVE_LDS > 4 * G::PART) ? 4 * G::WAVE_LDS : 4 * G::PART;
   const int lds_floats = v2 ? G2::LDS_FLOATS : lds1;
   const long units = v2 ? (long)a0.nb * G2::NG : ((long)a0.nb * G::HOUT + 3) / 4;
-  long blocks = (v2 ? 2L : 1L) * drq_num_cus();
+  // conv1 (SMALL): 63 MFMAs per output row against 38 staging loads + LDS writes that the wave cannot overlap with
+  // its own MFMAs; its tile is 15 KB per wave and it needs 180 VGPRs, so two workgroups share a CU and one's staging
+  // runs under the other's MFMAs
+  long blocks = ((v2 || G::SMALL) ? 2L : 1L) * drq_num_cus();
   if (blocks > units) blocks = units;
   if (blocks < 1) blocks = 1;
   if ((size_t)blocks * G::PART * sizeof(float) > ws_bytes) return DRQ_EWS;
