@@ -619,26 +619,51 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad2_kernel(WgradArgs a) {
 // 7 steps later, into the ring slot / dY buffer the loop does not read), so staging hides under the MFMAs
 // although the wave is alone on its SIMD.  Disabled loads are sent out of range of the buffer descriptor
 // instead of being branched around (branches would force vmcnt(0) waits).
-template <int HIN>
-__global__ __launch_bounds__(256, 1) void conv3x3_wgrad3_kernel(WgradArgs a) {
+unsigned long long* g_wgrad_stamps = nullptr;   // set by drq_dev_wgrad_stamps (undeclared development hook)
+
+// The k-step loop is written for a wave that is alone on its SIMD.  Measured there (tools/mfma_issue_probe.hip):
+// every VALU instruction between the MFMAs costs ~5 cycles of matrix-pipe time (LDS and scalar instructions cost
+// ~1), so the loop keeps the vector ALU out of the staging path altogether: all per-row / per-piece address
+// arithmetic is wave-uniform and lives in SGPRs (each staging load gets its own buffer descriptor: base and byte
+// count advanced by scalar adds, which also keeps the hardware range check exact), the per-lane parts of the
+// global and LDS addresses are loop invariants, and lanes that have nothing to load mirror a neighbour (same
+// address, same value, same LDS destination) instead of being masked.
+template <int HIN, bool STAMP = false>
+__global__ __launch_bounds__(256, 1) void conv3x3_wgrad3_kernel(WgradArgs a, unsigned long long* stamps = nullptr) {
   constexpr int CIN = 32;
   using G = WgradGeom<CIN, HIN, 1>;
   constexpr int HOUT = G::HOUT, KS = G::KS, XP = G::XP, DP = G::DP, NT = 9;
   constexpr int XJ = G::XJ, DJ = G::DJ, XRPI = G::XRPI, DRPI = G::DRPI;
   constexpr int RS = CIN * XP;            // floats per ring slot (one input row, all channels)
   constexpr int DS = 32 * DP;             // floats per dY buffer
-  constexpr int WAVE = 4 * RS + 2 * DS + 128;     // + a 64-lane x 8-byte dump row for disabled stores
+  constexpr int WAVE = 4 * RS + 2 * DS + 128;
   static_assert(KS >= 18, "staging schedule needs 18 k-steps");
+  static_assert(WAVE % 4 == 0, "16-byte zero fill");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63;
-  const int wid = threadIdx.x >> 6;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col = lane & 31;
   const int half = lane >> 5;
   float* ring = smem + wid * WAVE;
   float* dyb = ring + 4 * RS;
-  float* dump = dyb + 2 * DS + 2 * lane;          // disabled LDS stores land here: no branch around a store,
-                                                  // so hipcc cannot sink the matching load behind a vmcnt(0)
-  for (int i = lane; i < WAVE; i += 64) ring[i] = 0.f;     // pad columns stay finite / zero
+  unsigned long long* stamp = nullptr;            // development only: 32 per wave; [30], [29] = wall clock start / end
+  int nstamp = 0;
+  if (STAMP) {
+    stamp = stamps + ((size_t)blockIdx.x * 4 + wid) * 32;
+    if (lane == 0) stamp[30] = __builtin_amdgcn_s_memrealtime();
+  }
+  auto mark = [&]() {
+    if (STAMP) {
+      if (nstamp < 28 && lane == 0) stamp[nstamp] = __builtin_amdgcn_s_memtime();
+      ++nstamp;
+    }
+  };
+  mark();
+  auto zero_fill = [&]() {                        // pad columns stay finite / zero
+    float4* r4 = reinterpret_cast<float4*>(ring);
+#pragma unroll 4
+    for (int i = lane; i < WAVE / 4; i += 64) r4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  };
 
   const int bbase = col * XP + half;      // B operand: X[pixel][ci]
   const int abase = col * DP + half;      // A operand: dY[cout][pixel]
@@ -650,93 +675,83 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad3_kernel(WgradArgs a) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float bsum = 0.f;
 
-  const long units = (long)a.nb * HOUT;
-  const long nw = (long)gridDim.x * 4;
-  const long gw = (long)blockIdx.x * 4 + wid;
-  const long u0 = units * gw / nw, u1 = units * (gw + 1) / nw;
+  // rows of this wave: units split evenly, the first `rem` waves take one more (all scalar)
+  const int units = a.nb * HOUT;
+  const int nw = (int)gridDim.x * 4;
+  const int gw = (int)blockIdx.x * 4 + wid;
+  const int per = units / nw, rem = units - per * nw;
+  const int u0 = gw * per + (gw < rem ? gw : rem);
+  const int u1 = u0 + per + (gw < rem ? 1 : 0);
 
-  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
-  const int xr = lane / G::XPAIRS, xpr = lane - xr * G::XPAIRS;
-  const int dr = lane / G::DPAIRS, dpr = lane - dr * G::DPAIRS;
-  const bool xact = xr < XRPI, dact = dr < DRPI;
-  const int xg_lane = (xr * HIN * HIN + 2 * xpr) * 4;
-  const int dg_lane = (int)(dr * a.dy_cs + 2 * dpr) * 4;
-  const int xl_lane = xr * XP + 2 * xpr;
-  const int dl_lane = dr * DP + 2 * dpr;
-  const bool d_last_odd = (HOUT & 1) && dpr == G::DPAIRS - 1;
-  constexpr int OOB = 0x7ffffff0;
+  // lane -> (row of the piece, 8-byte pair of the row); lanes past the piece and, in the last piece, rows past
+  // channel 31 mirror the last valid lane
+  constexpr int XLASTR = CIN - 1 - (XJ - 1) * XRPI, DLASTR = 31 - (DJ - 1) * DRPI;   // last valid row of the last piece
+  const int xr0 = lane / G::XPAIRS, dr0 = lane / G::DPAIRS;
+  const int xr = xr0 < XRPI ? xr0 : XRPI - 1, xpr = xr0 < XRPI ? lane - xr0 * G::XPAIRS : G::XPAIRS - 1;
+  const int dr = dr0 < DRPI ? dr0 : DRPI - 1, dpr = dr0 < DRPI ? lane - dr0 * G::DPAIRS : G::DPAIRS - 1;
+  const int xrl = xr < XLASTR ? xr : XLASTR, drl = dr < DLASTR ? dr : DLASTR;
+  const int xg_full = (xr * HIN * HIN + 2 * xpr) * 4, xg_last = (xrl * HIN * HIN + 2 * xpr) * 4;   // global, bytes
+  const int dg_full = (int)(dr * a.dy_cs + 2 * dpr) * 4, dg_last = (int)(drl * a.dy_cs + 2 * dpr) * 4;
+  const int xl_full = xr * XP + 2 * xpr, xl_last = xrl * XP + 2 * xpr;                            // LDS, floats
+  const int dl_full = dr * DP + 2 * dpr, dl_last = drl * DP + 2 * dpr;
+  typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+  const unsigned long xaddr = (unsigned long)a.x, daddr = (unsigned long)a.dy;
+  const unsigned x_bytes = a.x_bytes, dy_bytes = a.dy_bytes;
+  constexpr unsigned XSTEP = XRPI * HIN * HIN * 4;          // bytes between the pieces of an input row
+  const unsigned d_step = (unsigned)a.dy_cs * 4u * DRPI;
+  const unsigned d_bs4 = (unsigned)a.dy_bs * 4u, d_rs4 = (unsigned)a.dy_rs * 4u, d_off4 = (unsigned)a.dy_off * 4u;
+
   // Hand-placed staging loads (inline asm, invisible to hipcc's scheduler and waitcnt pass, which otherwise sinks
   // every load next to its LDS store and waits for it at once).  Their completion is counted by hand below:
   // loads and only loads are outstanding inside the k-step loop, vmcnt retires them in issue order.
-  typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-  const unsigned long xaddr = (unsigned long)a.x, daddr = (unsigned long)a.dy;
-  const u32x4v xsrd = {(unsigned)xaddr, (unsigned)(xaddr >> 32) & 0xffffu, a.x_bytes, 0x00020000u};
-  const u32x4v dsrd = {(unsigned)daddr, (unsigned)(daddr >> 32) & 0xffffu, a.dy_bytes, 0x00020000u};
-  // only the last piece of a row group is partial: two lane masks per operand instead of one per piece
-  // (eleven hoisted 64-bit masks per operand exhaust the SGPRs)
-  const bool okx_full = xact, okx_last = xact && (XJ - 1) * XRPI + xr < CIN;
-  const bool okd_full = dact, okd_last = dact && (DJ - 1) * DRPI + dr < 32;
-
-  // load piece j of input row `row` of sample b / of the dY row (b, oy); `on` is wave-uniform
-  // (piece offsets are folded into the per-lane offset with literal adds and soffset stays 0: a scalar offset
-  //  per piece costs one SGPR each, and under SGPR pressure hipcc moves the buffer descriptor to VGPRs and wraps
-  //  every load in a waterfall loop)
-  auto ld_x = [&](int j, int b, int row, bool on) {
-    const bool ok = on && (j == XJ - 1 ? okx_last : okx_full);
-    const int voff = ok ? ((b * CIN * HIN + row) * HIN) * 4 + xg_lane + j * (XRPI * HIN * HIN * 4) : OOB;
-    return __builtin_amdgcn_raw_buffer_load_b64(xrsrc, voff, 0, 0);
+  // `off` = byte offset of the piece (wave-uniform); a disabled load gets a zero-length buffer and returns 0.
+  auto ld_asm = [&](u32x2& dst, unsigned long base, unsigned bytes, unsigned off, int lane_off, bool on) {
+    const unsigned long p = base + off;
+    const u32x4v srd = {(unsigned)p, (unsigned)(p >> 32) & 0xffffu, on && off < bytes ? bytes - off : 0u, 0x00020000u};
+    asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(lane_off), "s"(srd) : "memory");
   };
-  auto ld_x_asm = [&](u32x2& dst, int j, int b, int row, bool on) {
-    const bool ok = on && (j == XJ - 1 ? okx_last : okx_full);
-    const int voff = ok ? ((b * CIN * HIN + row) * HIN) * 4 + xg_lane + j * (XRPI * HIN * HIN * 4) : OOB;
-    asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(xsrd) : "memory");
-  };
-  auto st_x = [&](int j, int slot, u32x2 v, bool on) {
-    const bool ok = on && (j == XJ - 1 ? okx_last : okx_full);
-    *reinterpret_cast<u32x2*>(ok ? ring + slot * RS + j * XRPI * XP + xl_lane : dump) = v;
-  };
-  const int d_bs4 = (int)a.dy_bs * 4, d_rs4 = (int)a.dy_rs * 4, d_off4 = (int)a.dy_off * 4;
-  const int d_step = (int)a.dy_cs * 4 * DRPI;
-  auto ld_d = [&](int j, int b, int oy, bool on) {
-    const bool ok = on && (j == DJ - 1 ? okd_last : okd_full);
-    const int voff = ok ? d_off4 + b * d_bs4 + oy * d_rs4 + dg_lane + j * d_step : OOB;
-    return __builtin_amdgcn_raw_buffer_load_b64(drsrc, voff, 0, 0);
-  };
-  auto ld_d_asm = [&](u32x2& dst, int j, int b, int oy, bool on) {
-    const bool ok = on && (j == DJ - 1 ? okd_last : okd_full);
-    const int voff = ok ? d_off4 + b * d_bs4 + oy * d_rs4 + dg_lane + j * d_step : OOB;
-    asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(voff), "s"(dsrd) : "memory");
-  };
-  auto st_d = [&](int j, int buf, u32x2 v, bool on) {
-    const bool ok = on && (j == DJ - 1 ? okd_last : okd_full);
-    if (d_last_odd) v[1] = 0u;            // column HOUT of an odd row pairs with the pad pixel: keep it zero
-    *reinterpret_cast<u32x2*>(ok ? dyb + buf * DS + j * DRPI * DP + dl_lane : dump) = v;
-  };
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
   // (re)start of a sample: three input rows into ring slots 0..2 (not overlapped; once per sample and wave start)
-  auto prime_x = [&](int b, int oy) {
+  auto prime_x = [&](int b, int oy, bool first) {
+    u32x2 t[3][XJ];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      u32x2 t[XJ];
+    for (int k = 0; k < 3; ++k)
 #pragma unroll
-      for (int j = 0; j < XJ; ++j) t[j] = ld_x(j, b, oy + k, true);
-#pragma unroll
-      for (int j = 0; j < XJ; ++j) st_x(j, k, t[j], true);
+      for (int j = 0; j < XJ; ++j)
+        t[k][j] = __builtin_amdgcn_raw_buffer_load_b64(
+            xrsrc, (j == XJ - 1 ? xg_last : xg_full) + j * (int)XSTEP, ((b * CIN * HIN + oy + k) * HIN) * 4, 0);
+    if (first) {                          // the zero fill of the tile runs while the first loads are in flight
+      __builtin_amdgcn_sched_barrier(0);
+      zero_fill();
+      __builtin_amdgcn_sched_barrier(0);
     }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int j = 0; j < XJ; ++j)
+        *reinterpret_cast<u32x2*>(ring + k * RS + j * XRPI * XP + (j == XJ - 1 ? xl_last : xl_full)) = t[k][j];
   };
 
   int slot = 0, dbuf = 0;
   if (u0 < u1) {
-    const int b = (int)(u0 / HOUT), oy = (int)(u0 - (long)b * HOUT);
-    prime_x(b, oy);
+    const int b = u0 / HOUT, oy = u0 - b * HOUT;
     u32x2 t[DJ];
 #pragma unroll
-    for (int j = 0; j < DJ; ++j) t[j] = ld_d(j, b, oy, true);
+    for (int j = 0; j < DJ; ++j)
+      t[j] = __builtin_amdgcn_raw_buffer_load_b64(drsrc, (j == DJ - 1 ? dg_last : dg_full) + (int)(j * d_step),
+                                                  (int)(d_off4 + b * d_bs4 + oy * d_rs4), 0);
+    prime_x(b, oy, true);
 #pragma unroll
-    for (int j = 0; j < DJ; ++j) st_d(j, 0, t[j], true);
+    for (int j = 0; j < DJ; ++j)
+      *reinterpret_cast<u32x2*>(dyb + j * DRPI * DP + (j == DJ - 1 ? dl_last : dl_full)) = t[j];
+  } else {
+    zero_fill();
   }
-  for (long u = u0; u < u1; ++u) {
-    const int b = (int)(u / HOUT), oy = (int)(u - (long)b * HOUT);
+  mark();
+  for (int u = u0; u < u1; ++u) {
+    mark();
+    const int b = u / HOUT, oy = u - b * HOUT;
     const bool has_next = u + 1 < u1;
     const bool same = has_next && oy + 1 < HOUT;          // next row belongs to the same sample
     const int nb = same ? b : b + 1, noy = same ? oy + 1 : 0;
@@ -744,16 +759,60 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad3_kernel(WgradArgs a) {
     const int rb0 = bbase + ((slot + 0) & 3) * RS, rb1 = bbase + ((slot + 1) & 3) * RS,
               rb2 = bbase + ((slot + 2) & 3) * RS;
     const float* da = dyb + dbuf * DS + abase;
+    const unsigned xrow = (unsigned)((b * CIN * HIN + oy + 3) * HIN) * 4u;     // staged input row (same sample only)
+    const unsigned drow = d_off4 + nb * d_bs4 + noy * d_rs4;                   // staged dY row
+    float* px_full = ring + wslot * RS + xl_full;
+    float* px_last = ring + wslot * RS + xl_last;
+    float* pd_full = dyb + (dbuf ^ 1) * DS + dl_full;
+    float* pd_last = dyb + (dbuf ^ 1) * DS + dl_last;
     u32x2 sx[XJ], sd[DJ];
+    // MFMA operands are read from LDS one k-step ahead (register double buffer), in three groups placed between
+    // the MFMAs of the current step; the staging instructions sit between later MFMAs.  sched_barrier pins that
+    // order (left alone, hipcc issues the reads of a step right before their first use).
+    auto rd_row = [&](int ky, int s, float* bv) {
+      const int rb = ky == 0 ? rb0 : (ky == 1 ? rb1 : rb2);
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) bv[ky * 3 + kx] = ring[rb + kx + 2 * s];
+    };
+    float cav = da[0], cbv[NT];
+    rd_row(0, 0, cbv);
+    rd_row(1, 0, cbv);
+    rd_row(2, 0, cbv);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
+      static_assert(XJ == DJ && XJ == 11, "hand-counted schedule assumes 11 pieces per row");
+      float nav = 0.f, nbv[NT];
+      const bool more = s + 1 < KS;
+      bsum += cav;
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cav, cbv[0], acc[0], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) {
+        nav = da[2 * (s + 1)];
+        // an odd row's last pixel pair is (HOUT-1, pad): the pad's dY (the next row's first value in LDS) is zero
+        if ((HOUT & 1) && s + 1 == KS - 1) nav = half ? 0.f : nav;
+        rd_row(0, s + 1, nbv);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cav, cbv[1], acc[1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) rd_row(1, s + 1, nbv);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(cav, cbv[2], acc[2], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) rd_row(2, s + 1, nbv);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(cav, cbv[3], acc[3], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
       // ---- staging for the next unit: piece s of the input row and of the dY row is loaded in step s (s < 11)
       // and written to LDS in step s+7; N = loads issued after the pair being retired
-      static_assert(XJ == DJ && XJ == 11, "hand-counted schedule assumes 11 pieces per row");
       if (s < XJ) {
-        ld_x_asm(sx[s], s, b, oy + 3, same);
-        ld_d_asm(sd[s], s, nb, noy, has_next);
+        ld_asm(sx[s], xaddr, x_bytes, xrow + s * XSTEP, s == XJ - 1 ? xg_last : xg_full, same);
+        ld_asm(sd[s], daddr, dy_bytes, drow + s * d_step, s == DJ - 1 ? dg_last : dg_full, has_next);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(cav, cbv[4], acc[4], 0, 0, 0);
+      acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(cav, cbv[5], acc[5], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
       if (s >= 7 && s - 7 < XJ) {
         constexpr int LAST = XJ - 1;                       // last step that issues loads
         const int n_after = 2 * ((s < LAST ? s : LAST) - (s - 7));
@@ -767,21 +826,23 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad3_kernel(WgradArgs a) {
           case 2: asm volatile("s_waitcnt vmcnt(2)" : "+v"(sx[s - 7]), "+v"(sd[s - 7])); break;
           default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(sx[s - 7]), "+v"(sd[s - 7])); break;
         }
-        st_x(s - 7, wslot, sx[s - 7], same);
-        st_d(s - 7, dbuf ^ 1, sd[s - 7], has_next);
+        // a disabled load returned zeros: storing them is harmless (the ring slot / dY buffer written here is
+        // re-primed or rewritten before it is read again)
+        const int j = s - 7;
+        *reinterpret_cast<u32x2*>((j == XJ - 1 ? px_last : px_full) + j * XRPI * XP) = sx[j];
+        *reinterpret_cast<u32x2*>((j == DJ - 1 ? pd_last : pd_full) + j * DRPI * DP) = sd[j];
       }
-      // ---- the MFMAs of pixel pair s
-      const float av = da[2 * s];
-      bsum += av;
+      __builtin_amdgcn_sched_barrier(0);
+      acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(cav, cbv[6], acc[6], 0, 0, 0);
+      acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(cav, cbv[7], acc[7], 0, 0, 0);
+      acc[8] = __builtin_amdgcn_mfma_f32_32x32x2f32(cav, cbv[8], acc[8], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      cav = nav;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int rb = (t / 3) == 0 ? rb0 : ((t / 3) == 1 ? rb1 : rb2);
-        const float bv = ring[rb + (t % 3) + 2 * s];
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
-      }
+      for (int t = 0; t < NT; ++t) cbv[t] = nbv[t];
     }
     if (has_next && !same) {
-      prime_x(nb, 0);
+      prime_x(nb, 0, false);
       slot = 0;
     } else {
       slot = (slot + 1) & 3;
@@ -790,7 +851,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad3_kernel(WgradArgs a) {
   }
 
   // ---- reduce the 4 waves of the block through LDS, one partial record per block
+  mark();
   __syncthreads();
+  mark();
   float* red = smem;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -798,9 +861,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad3_kernel(WgradArgs a) {
     for (int r = 0; r < 16; ++r) red[wid * G::PART + t * 1024 + r * 64 + lane] = acc[t][r];
   red[wid * G::PART + NT * 1024 + lane] = bsum;
   __syncthreads();
-  float* out = a.part + (long)blockIdx.x * G::PART;
-  for (int i = threadIdx.x; i < G::PART; i += 256)
-    out[i] = (red[i] + red[G::PART + i]) + (red[2 * G::PART + i] + red[3 * G::PART + i]);
+  static_assert(G::PART % 4 == 0, "16-byte record reduction");
+  float4* out = reinterpret_cast<float4*>(a.part + (long)blockIdx.x * G::PART);
+  const float4* r4 = reinterpret_cast<const float4*>(red);
+  for (int i = threadIdx.x; i < G::PART / 4; i += 256) {
+    const float4 p = r4[i], q = r4[G::PART / 4 + i], v = r4[2 * (G::PART / 4) + i], w = r4[3 * (G::PART / 4) + i];
+    out[i] = make_float4((p.x + q.x) + (v.x + w.x), (p.y + q.y) + (v.y + w.y), (p.z + q.z) + (v.z + w.z),
+                         (p.w + q.w) + (v.w + w.w));
+  }
+  mark();
+  if (STAMP && lane == 0) {
+    stamp[29] = __builtin_amdgcn_s_memrealtime();
+    stamp[28] = (unsigned long long)nstamp;
+  }
 }
 
 // Sums the per-block partial records in a fixed order and scatters to the canonical layouts.
@@ -973,6 +1046,7 @@ int launch_wgrad(const WgradArgs& a0, float* dw, float* db, float* ws, size_t ws
   if (blocks > units) blocks = units;
   if (blocks < 1) blocks = 1;
   if ((size_t)blocks * G::PART * sizeof(float) > ws_bytes) return DRQ_EWS;
+  if (((size_t)ws & 15) != 0) return DRQ_EARG;          // partial records are written 16 bytes at a time
   WgradArgs a = a0;
   a.part = ws;
   static bool attr_set = false;
@@ -997,7 +1071,16 @@ int launch_wgrad(const WgradArgs& a0, float* dw, float* db, float* ws, size_t ws
         if (e != hipSuccess) return (int)e;
         attr3 = true;
       }
-      hipLaunchKernelGGL((conv3x3_wgrad3_kernel<HIN>), dim3((unsigned)blocks), dim3(256), lds3 * 4, st, a);
+      if (HIN == 41 && g_wgrad_stamps) {
+        hipFuncSetAttribute((const void*)conv3x3_wgrad3_kernel<41, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            lds3 * 4);
+        WgradArgs as = a;
+        if (getenv("DRQ_WGRAD_NOLOAD")) as.x_bytes = as.dy_bytes = 0;     // every load out of range: no memory traffic
+        hipLaunchKernelGGL((conv3x3_wgrad3_kernel<41, true>), dim3((unsigned)blocks), dim3(256), lds3 * 4, st, as,
+                           g_wgrad_stamps);
+      } else
+      hipLaunchKernelGGL((conv3x3_wgrad3_kernel<HIN>), dim3((unsigned)blocks), dim3(256), lds3 * 4, st, a,
+                         (unsigned long long*)nullptr);
       DRQ_LAUNCH_CHECK();
       if (nblocks_out) *nblocks_out = (int)blocks;
       if (defer) return DRQ_OK;
@@ -1067,6 +1150,7 @@ extern "C" {
 
 // development hook (not part of the ABI): device buffer of 32 u64 per wave for DRQ_CONV_VARIANT=10
 void drq_dev_conv_stamps(void* p) { g_conv_stamps = (unsigned long long*)p; }
+void drq_dev_wgrad_stamps(void* p) { g_wgrad_stamps = (unsigned long long*)p; }
 void drq_dev_conv_variant(int v) { g_conv_variant = v; }
 
 // y = relu?(conv3x3(x, w) + bias); x [nb][cin][hin][hin], y written with the given strides.
