@@ -382,6 +382,8 @@ int drq_skinny_dgrad(const float* dz, long lda, const float* w, long ldb, float*
                      const float* aux, int ldaux, int scatter_hw, hipStream_t st);
 
 // gemm2.hip
+int drq_trunk_fwd_partial(int nbatch, const float* const* A, long lda, const float* const* B, long ldb, int M, int N,
+                          int K, float* ws, size_t ws_bytes, int* splitk_out, hipStream_t st);
 int drq_gemm2(int nbatch, const float* const* A, long lda, int a_kc, const float* const* B, long ldb, int b_kc,
               float* const* C, long ldc, int M, int N, int K, const float* const* bias, int relu,
               const float* const* aux, int ldaux, float* const* rowsum, hipStream_t st);
@@ -456,6 +458,16 @@ int drq_gemm_batched_f32(int nbatch, const float* const* A, long lda, int a_kc, 
 int drq_gemm_batched_partial(int nbatch, const float* const* A, long lda, int a_kc, const float* const* B, long ldb,
                              int b_kc, float* const* C, long ldc, int M, int N, int K, const float* const* bias,
                              float* ws, size_t ws_bytes, int* splitk_out, hipStream_t st) {
+  // the trunk forward (k-contiguous operands, N <= 64, long K) has its own kernel
+  if (a_kc && b_kc && N <= 64 && K >= 4096 && ldc == N && !getenv("DRQ_NO_TRUNK_KERNEL")) {
+    int sk = 1;
+    const int rc = drq_trunk_fwd_partial(nbatch, A, lda, B, ldb, M, N, K, ws, ws_bytes, &sk, st);
+    if (rc == DRQ_OK) {
+      if (splitk_out) *splitk_out = sk;
+      return DRQ_OK;
+    }
+    if (rc != DRQ_EARG) return rc;
+  }
   g_leave_partials = true;
   g_last_splitk = 1;
   const int rc = drq_gemm_batched_f32(nbatch, A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, bias, 0, nullptr, 0, nullptr,

@@ -6,10 +6,13 @@
 // (45-50 % of the MFMA rate whatever the tile shape or k-tile).  Here a wave owns a 32x32 output tile and feeds
 // v_mfma_f32_32x32x2_f32 straight from global memory, the way the conv kernel does:
 //   * lane (i = lane&31, h = lane>>5) holds row i of the A tile / column i of the B tile and, in each 32-long
-//     k-step, the 16 consecutive k values [16h, 16h+16).  MFMA e of the step multiplies the e-th of them, i.e.
-//     reduces k = e and k = 16+e: any k order is a valid reduction as long as A and B use the same one.
-//   * k-contiguous operand (x[m][k], W[n][k]): four 16-byte buffer loads per lane and step; a lane reads 64 B
-//     of its row, the two halves of the wave cover the whole 128-byte line in the same instruction pair.
+//     k-step, the 16 k values 8q + 4h + {0..3}, q = 0..3.  MFMA e = 4q + j of the step multiplies the e-th of
+//     them, i.e. reduces k = 8q + j and k = 8q + 4 + j: any k order is a valid reduction as long as A and B use
+//     the same one.
+//   * k-contiguous operand (x[m][k], W[n][k]): four 16-byte buffer loads per lane and step; load q of the two
+//     lanes of a row covers 32 contiguous bytes, so an instruction touches one 64-byte sector per row (with the
+//     lane's 16 values contiguous instead, the two lanes hit both sectors of the line and the L1 does twice the
+//     sector reads).
 //   * row-contiguous operand (W[k][n] in dgrad, dy[k][m] and x[k][n] in wgrad): 16 dword buffer loads per step,
 //     each two full 128-byte row segments.
 //   * no LDS, no barrier in the main loop; the loads of step s+1 are issued before the MFMAs of step s and
@@ -47,14 +50,15 @@ __device__ __forceinline__ void load_step(float (&v)[16], __amdgpu_buffer_rsrc_t
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f32x4 t = __builtin_bit_cast(
-          f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + q * 16, 0));
+          f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + q * 32, 0));
       const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
       v[q * 4 + 0] = t0; v[q * 4 + 1] = t1; v[q * 4 + 2] = t2; v[q * 4 + 3] = t3;
     }
   } else {
 #pragma unroll
     for (int e = 0; e < 16; ++e)
-      v[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff + e * ldbytes, 0));
+      v[e] = __uint_as_float(
+          __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff + (8 * (e >> 2) + (e & 3)) * ldbytes, 0));
   }
 }
 
@@ -80,10 +84,10 @@ __global__ __launch_bounds__(256) void gemm2_kernel(G2Args g) {
   const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)g.B[batch], 0, g.b_bytes, 0x00020000);
   const unsigned lda4 = (unsigned)g.lda * 4, ldb4 = (unsigned)g.ldb * 4;
   // per-lane byte offset of the lane's first element of step 0; the step advances through the scalar offset
-  const unsigned avoff = A_KC ? ((unsigned)(m0 + col) * lda4 + (unsigned)(kbeg + half * 16) * 4)
-                              : ((unsigned)(kbeg + half * 16) * lda4 + (unsigned)(m0 + col) * 4);
-  const unsigned bvoff = B_KC ? ((unsigned)(n0 + col) * ldb4 + (unsigned)(kbeg + half * 16) * 4)
-                              : ((unsigned)(kbeg + half * 16) * ldb4 + (unsigned)(n0 + col) * 4);
+  const unsigned avoff = A_KC ? ((unsigned)(m0 + col) * lda4 + (unsigned)(kbeg + half * 4) * 4)
+                              : ((unsigned)(kbeg + half * 4) * lda4 + (unsigned)(m0 + col) * 4);
+  const unsigned bvoff = B_KC ? ((unsigned)(n0 + col) * ldb4 + (unsigned)(kbeg + half * 4) * 4)
+                              : ((unsigned)(kbeg + half * 4) * ldb4 + (unsigned)(n0 + col) * 4);
   const unsigned astep = A_KC ? 128u : 32u * lda4;   // bytes per k-step
   const unsigned bstep = B_KC ? 128u : 32u * ldb4;
 
@@ -179,7 +183,156 @@ int launch2(const G2Args& g, int nbatch, hipStream_t st) {
   return DRQ_OK;
 }
 
+// ---- trunk forward: z = feat W^T with K = repr_dim (39200), N = feature_dim (50) (drqv2.py:71-72,91-92) --------
+// Both operands are k-contiguous and N fits two 32-column tiles, so a wave takes TM row tiles x both column tiles
+// and a slice of K: per 32-long k-step it loads 4*(TM+2) 16-byte pieces per lane for 32*TM MFMAs -- half (TM = 1)
+// or a third (TM = 2) of the loads per MFMA of the one-tile form above, which the texture addresser keeps up
+// with.  Weight rows >= N are out of the buffer's range and read as zero.  K is cut into gridDim.x slices
+// (whole k-steps, sizes differing by at most one step); the four waves of a workgroup sum their shares in wave
+// order through LDS and the workgroup writes ONE partial record [M][N] per (problem, blockIdx.x) in the split-K
+// layout of gemm.hip, which the LayerNorm kernel sums (+ bias) in a fixed order.  No VALU work in the k loop.
+struct TrunkArgs {
+  const float* A[MAXB2];
+  const float* B[MAXB2];
+  float* part;               // [nbatch][gridDim.x][M][N]
+  long lda, ldb;
+  int M, N, K;
+  unsigned a_bytes, b_bytes;
+};
+
+template <int TM>
+__global__ __launch_bounds__(256, 1) void trunk_fwd_kernel(TrunkArgs g) {
+  __shared__ float red[3 * TM * 2 * 16 * 64];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col = lane & 31, half = lane >> 5;
+  const int batch = blockIdx.z;
+  const int m0 = blockIdx.y * (32 * TM);
+  const int steps = g.K >> 5;
+  // the workgroup's slice of k-steps, dealt round-robin to its four waves: at any time the workgroup reads
+  // 512 contiguous bytes of each row instead of four distant 128-byte pieces
+  const int nsl = (int)gridDim.x, sl = (int)blockIdx.x;
+  const int per = steps / nsl, rem = steps - per * nsl;
+  const int s0 = sl * per + (sl < rem ? sl : rem) + wid;
+  const int len = per + (sl < rem ? 1 : 0);
+  const int ns = len > wid ? (len - wid + 3) / 4 : 0;
+
+  const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void*)g.A[batch], 0, g.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)g.B[batch], 0, g.b_bytes, 0x00020000);
+  const unsigned lda4 = (unsigned)g.lda * 4, ldb4 = (unsigned)g.ldb * 4;
+  unsigned avoff[TM], bvoff[2];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) avoff[i] = (unsigned)(m0 + i * 32 + col) * lda4 + (unsigned)(half * 4) * 4;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bvoff[j] = (unsigned)(j * 32 + col) * ldb4 + (unsigned)(half * 4) * 4;
+
+  f32x16 acc[TM][2];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // two register stages (a third, i.e. loads issued two k-steps ahead, measured slower: 53.6 vs 51.4 us)
+  float a0[TM][16], b0[2][16], a1[TM][16], b1[2][16];
+  auto load = [&](float (&a)[TM][16], float (&b)[2][16], int s) {
+    const int sc = s < ns ? s : ns - 1;                   // past the end: harmless re-load of the last step
+    const unsigned so = (unsigned)(s0 + 4 * sc) * 128u;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) load_step<true>(a[i], ars, avoff[i], so, lda4);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) load_step<true>(b[j], brs, bvoff[j], so, ldb4);
+  };
+  auto mfma_step = [&](const float (&a)[TM][16], const float (&b)[2][16]) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+  };
+  if (ns > 0) {
+    load(a0, b0, 0);
+    int s = 0;
+    for (; s + 2 <= ns; s += 2) {
+      load(a1, b1, s + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(a0, b0);
+      load(a0, b0, s + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(a1, b1);
+    }
+    if (s < ns) mfma_step(a0, b0);
+  }
+
+  // ---- sum the four slices of the workgroup in wave order, write the partial record
+  if (wid > 0) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(((wid - 1) * TM + i) * 2 + j) * 1024 + r * 64 + lane] = acc[i][j][r];
+  }
+  __syncthreads();
+  if (wid > 0) return;
+  float* out = g.part + ((long)batch * gridDim.x + blockIdx.x) * g.M * g.N;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = j * 32 + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[i][j][r];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) v += red[((w * TM + i) * 2 + j) * 1024 + r * 64 + lane];
+        if (n < g.N) out[(long)(m0 + i * 32 + rowmap2(r, half)) * g.N + n] = v;
+      }
+    }
+}
+
 }  // namespace
+
+// internal (gemm.hip): split-K partials [nbatch * (*splitk_out)][M][N] of A[b] B[b]^T for the trunk shape.
+// Returns DRQ_EARG when the problem is not eligible (the caller then uses the LDS-tiled kernel).
+int drq_trunk_fwd_partial(int nbatch, const float* const* A, long lda, const float* const* B, long ldb, int M, int N,
+                          int K, float* ws, size_t ws_bytes, int* splitk_out, hipStream_t st) {
+  if (nbatch <= 0 || nbatch > MAXB2 || M % 32 || M < 32 || N < 1 || N > 64 || K % 32 || K < 4096) return DRQ_EARG;
+  if (lda % 4 || ldb % 4 || !ws || ((uintptr_t)ws & 15)) return DRQ_EARG;
+  const size_t ab = (size_t)M * lda * 4, bb = (size_t)N * ldb * 4;
+  if (ab >= (1ull << 31) || bb >= (1ull << 31)) return DRQ_EARG;
+  TrunkArgs g{};
+  for (int b = 0; b < nbatch; ++b) {
+    if (((uintptr_t)A[b] & 15) || ((uintptr_t)B[b] & 15)) return DRQ_EARG;
+    g.A[b] = A[b]; g.B[b] = B[b];
+  }
+  g.part = ws; g.lda = lda; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
+  g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
+  // one workgroup per CU (one wave per SIMD): measured 51 us against 59 us with two and 66 us with four for the
+  // four trunks of the critic update -- more concurrent row streams cost more in the memory system than the
+  // extra waves hide
+  const int steps = K / 32, cus = drq_num_cus();
+  const bool tm2 = M % 64 == 0 && (long)nbatch * (M / 32) * 4 >= 64;
+  const int rows = tm2 ? M / 64 : M / 32;
+  int blocks_k = (cus + nbatch * rows - 1) / (nbatch * rows);
+  if (blocks_k * 4 > steps) blocks_k = steps / 4;
+  if (const char* e = getenv("DRQ_TRUNK_DBG")) {        // development knobs
+    const int d = atoi(e);
+    if (d & 1) g.a_bytes = g.b_bytes = 0;               // every load out of range: MFMA time only
+    if (d & 2) blocks_k *= 2;
+  }
+  if (blocks_k < 2) return DRQ_EARG;      // a split count of 1 means "result in C" to the callers
+  if ((size_t)nbatch * blocks_k * M * N * sizeof(float) > ws_bytes) return DRQ_EWS;
+  const dim3 grid(blocks_k, rows, nbatch);
+  if (tm2) hipLaunchKernelGGL((trunk_fwd_kernel<2>), grid, dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((trunk_fwd_kernel<1>), grid, dim3(256), 0, st, g);
+  DRQ_LAUNCH_CHECK();
+  if (splitk_out) *splitk_out = blocks_k;
+  return DRQ_OK;
+}
 
 // Returns DRQ_EARG when the problem is not eligible (the caller then uses the LDS-tiled kernel).
 int drq_gemm2(int nbatch, const float* const* A, long lda, int a_kc, const float* const* B, long ldb, int b_kc,

@@ -212,6 +212,29 @@ def gemm_batched(As, a_kc, Bs, b_kc, M, N, K, lda, ldb, biases=None, relu=False,
     return Cs, rs
 
 
+def gemm_batched_partial(As, Bs, M, N, K, lda, ldb):
+    """Forward form (both operands k-contiguous) through the internal entry the update uses for the trunk:
+    returns (sum of the split-K partial records per problem [n][M][N], split count).  Test / tool helper."""
+    import ctypes
+    lib = _lib.load()
+    n = len(As)
+    dev = As[0].device
+    Cs = [torch.zeros((M, N), device=dev, dtype=torch.float32) for _ in range(n)]
+    ws = torch.zeros((16 * 1024 * 1024,), device=dev, dtype=torch.float32)
+    sk = ctypes.c_int(0)
+    fn = lib.drq_gemm_batched_partial
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_void_p, ctypes.c_long,
+                   ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]
+    check(fn(n, _ptr_array(As), lda, 1, _ptr_array(Bs), ldb, 1, _ptr_array(Cs), N, M, N, K, None, ptr(ws),
+             ws.numel() * 4, ctypes.byref(sk), _stream()), "drq_gemm_batched_partial")
+    k = sk.value
+    if k <= 1:
+        return torch.stack(Cs), k
+    return ws[: n * k * M * N].view(n, k, M, N).sum(dim=1), k
+
+
 def qout_fwd(hs, ws_, bs):
     lib = _lib.load()
     B, H = hs[0].shape

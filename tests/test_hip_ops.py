@@ -281,6 +281,19 @@ def test_gemm_batched_forward_four_problems(ops):
         assert nerr(c, ref) <= 3e-6
 
 
+@pytest.mark.parametrize("M,N,K,n", [(256, 50, 39200, 4), (256, 50, 39200, 1), (64, 50, 4096, 2), (32, 64, 4128, 1),
+                                     (96, 7, 8192, 3), (512, 50, 39200, 1)])
+def test_trunk_forward_partials(ops, M, N, K, n):
+    """the trunk kernel (z = feat W^T, k-contiguous operands, N <= 64, long K): row tiles of 32 and 64, slices of
+    unequal length, weight rows past N read as zero, one problem and several; the sum of its records is the GEMM."""
+    xs = [rnd(M, K, seed=i) for i in range(n)]
+    wts = [rnd(N, K, seed=5 + i, scale=K ** -0.5) for i in range(n)]
+    got, sk = ops.gemm_batched_partial([x.cuda() for x in xs], [w.cuda() for w in wts], M, N, K, K, K)
+    assert sk > 1
+    for i in range(n):
+        assert nerr(got[i], xs[i].double() @ wts[i].double().t()) <= 3e-6
+
+
 @pytest.mark.parametrize("B,H,n", [(256, 1024, 4), (7, 64, 2), (33, 100, 1)])
 def test_qout_fwd_bwd(ops, B, H, n):
     hs = [rnd(B, H, seed=i).clamp_min(0) for i in range(n)]
