@@ -382,6 +382,8 @@ int drq_skinny_dgrad(const float* dz, long lda, const float* w, long ldb, float*
                      const float* aux, int ldaux, int scatter_hw, hipStream_t st);
 
 // gemm2.hip
+int drq_trunk_wgrad(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K,
+                    float* rowsum, hipStream_t st);
 int drq_trunk_fwd_partial(int nbatch, const float* const* A, long lda, const float* const* B, long ldb, int M, int N,
                           int K, float* ws, size_t ws_bytes, int* splitk_out, hipStream_t st);
 int drq_gemm2(int nbatch, const float* const* A, long lda, int a_kc, const float* const* B, long ldb, int b_kc,
@@ -405,6 +407,12 @@ int drq_gemm_batched_f32(int nbatch, const float* const* A, long lda, int a_kc, 
       K <= 128 && !rowsum) {
     const int rc =
         drq_skinny_dgrad(A[0], lda, B[0], ldb, C[0], ldc, M, N, K, aux ? aux[0] : nullptr, ldaux, scatter_hw, st);
+    if (rc != DRQ_EARG) return rc;
+  }
+  // the trunk layer's weight gradient (M = feature_dim, N = 39200, K = batch) likewise
+  if (nbatch == 1 && tile == 0 && splitk == 0 && scatter_hw == 0 && !a_kc && !b_kc && M <= 64 && N >= 4096 && !bias &&
+      !relu && !aux) {
+    const int rc = drq_trunk_wgrad(A[0], lda, B[0], ldb, C[0], ldc, M, N, K, rowsum ? rowsum[0] : nullptr, st);
     if (rc != DRQ_EARG) return rc;
   }
   // hidden x hidden layers at multiple-of-32 shapes: the LDS-free kernel (gemm2.hip)

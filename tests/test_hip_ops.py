@@ -205,7 +205,9 @@ def test_unsupported_shapes_are_refused(ops):
 
 
 @pytest.mark.parametrize("Brows,N,K,n", [(256, 1024, 1024, 2), (9, 50, 39200, 1), (31, 1024, 56, 2), (12, 6, 1024, 1),
-                                         (40, 70, 33, 3), (256, 50, 39200, 1), (300, 100, 8192, 1), (5, 21, 4096, 1)])
+                                         (40, 70, 33, 3), (256, 50, 39200, 1), (300, 100, 8192, 1), (5, 21, 4096, 1),
+                                         (128, 50, 39200, 1), (256, 64, 4096, 1), (256, 33, 8192, 1),
+                                         (128, 1, 4128, 1)])
 def test_gemm_batched_wgrad_with_fused_bias_grad(ops, Brows, N, K, n):
     """dW_i = dy_i^T x_i and db_i = column sums of dy_i from ONE launch, independent pointers per problem"""
     dys = [rnd(Brows, N, seed=10 + i) for i in range(n)]

@@ -33,3 +33,22 @@ for n in (4, 1):
     ref = A[0].double() @ ws[0].double().t()
     err = float((got[0].double() - ref).abs().max() / ref.abs().max())
     print(f"problems={n}: median {ts[len(ts) // 2]:.1f} us  min {ts[0]:.1f} us  split {skc.value}  err {err:.2e}")
+
+# trunk weight gradient dW = dz^T feat (M = 50, N = 39200, K = batch)
+for Bk in (256, 128):
+    dz = torch.randn(Bk, N, device="cuda")
+    feat = torch.randn(Bk, K, device="cuda")
+    for _ in range(3):
+        (dw,), (db,) = ops.gemm_batched([dz], False, [feat], False, N, K, Bk, N, K, rowsum=True)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(20):
+        e0.record()
+        ops.gemm_batched([dz], False, [feat], False, N, K, Bk, N, K, rowsum=True, Cs=[dw])
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1000)
+    ts.sort()
+    ref = dz.double().t() @ feat.double()
+    err = float((dw.double() - ref).abs().max() / ref.abs().max())
+    print(f"wgrad batch={Bk}: median {ts[len(ts) // 2]:.1f} us (includes a 64 MB workspace allocation per call)  err {err:.2e}")
