@@ -81,6 +81,109 @@ __global__ void aug_kernel(const T* __restrict__ obs, const float* __restrict__ 
   }
 }
 
+// The same augmentation for uint8 frames with the source rows staged through LDS.  aug_kernel issues 4 byte
+// loads per channel and pixel (36 global load instructions per thread, 64 bytes each per wave): at 9x84x84 it is
+// bound by the texture addresser, not by memory (63 us for 163 MB).  Here a workgroup owns R output rows of one
+// sample: it copies the source rows those touch (all channels, usually R+1 rows of h bytes) into LDS with dword
+// loads, and the four taps become LDS byte reads.  Coordinates, weights, tap selection and the blend are the
+// statements of aug_kernel, so results are bit-identical; a row range that does not fit NR rows (not expected:
+// the grid is monotone with unit steps) reads its taps from global memory like aug_kernel.
+__global__ __launch_bounds__(256) void aug_rows_kernel(const uint8_t* __restrict__ obs, const float* __restrict__ shift,
+                                                       const float* __restrict__ base, float* __restrict__ out,
+                                                       int n, int c, int h, int pad, int fuse_norm,
+                                                       const uint8_t* __restrict__ obs1,
+                                                       const float* __restrict__ shift1, int R, int NR) {
+#pragma clang fp contract(off)
+  extern __shared__ unsigned aug_lds[];           // [c][NR][h/4] dwords
+  const int hw = h * h, hq = h >> 2;
+  const int b = blockIdx.y;
+  if (blockIdx.z == 1) {
+    obs = obs1;
+    shift = shift1;
+    out += (long)n * c * hw;
+  }
+  const int S = h + 2 * pad;
+  const float sc = (float)(2.0 / (double)S);
+  auto cl = [&](int v) { v -= pad; return v < 0 ? 0 : (v > h - 1 ? h - 1 : v); };
+  const float shx = shift[2 * b + 0] * sc, shy = shift[2 * b + 1] * sc;
+  auto coord = [&](int k, float sh, float& f) {   // unnormalised sample coordinate of grid index k
+    const float g = base[k] + sh;
+    const float v = ((g + 1.f) * (float)S - 1.f) / 2.f;
+    f = floorf(v);
+    return v;
+  };
+  const int i0 = blockIdx.x * R;
+  const int ilast = i0 + R - 1 < h - 1 ? i0 + R - 1 : h - 1;
+  float fa, fb;
+  coord(i0, shy, fa);
+  coord(ilast, shy, fb);
+  const int sy_lo = cl((int)fa), sy_hi = cl((int)fb + 1);       // the grid is increasing: rows in between lie inside
+  const int nrows = sy_hi - sy_lo + 1;
+  const bool staged = nrows >= 1 && nrows <= NR;
+  const uint8_t* src = obs + (long)b * c * hw;
+  if (staged) {
+    const int per_ch = nrows * hq;
+    for (int idx = threadIdx.x; idx < c * per_ch; idx += 256) {
+      const int ch = idx / per_ch, rem = idx - ch * per_ch;
+      const int r = rem / hq, q = rem - r * hq;
+      aug_lds[(ch * NR + r) * hq + q] =
+          reinterpret_cast<const unsigned*>(src + (long)ch * hw + (long)(sy_lo + r) * h)[q];
+    }
+  }
+  __syncthreads();
+  const int il = threadIdx.x / h, j = threadIdx.x - il * h;
+  const int i = i0 + il;
+  if (il >= R || i >= h) return;
+  float fx, fy;
+  const float ix = coord(j, shx, fx), iy = coord(i, shy, fy);
+  const int x0 = (int)fx, y0 = (int)fy;
+  const float wx1 = ix - fx, wx0 = (fx + 1.f) - ix;
+  const float wy1 = iy - fy, wy0 = (fy + 1.f) - iy;
+  const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;   // nw, ne, sw, se
+  const bool okx0 = x0 >= 0 && x0 < S, okx1 = x0 + 1 >= 0 && x0 + 1 < S;
+  const bool oky0 = y0 >= 0 && y0 < S, oky1 = y0 + 1 >= 0 && y0 + 1 < S;
+  const int sx0 = cl(x0), sx1 = cl(x0 + 1), sy0 = cl(y0), sy1 = cl(y0 + 1);
+  const bool k00 = okx0 && oky0, k01 = okx1 && oky0, k10 = okx0 && oky1, k11 = okx1 && oky1;
+  auto blend = [&](float t00, float t01, float t10, float t11) {
+    float v = 0.f;
+    if (k00) v = __fadd_rn(v, __fmul_rn(t00, w00));
+    if (k01) v = __fadd_rn(v, __fmul_rn(t01, w01));
+    if (k10) v = __fadd_rn(v, __fmul_rn(t10, w10));
+    if (k11) v = __fadd_rn(v, __fmul_rn(t11, w11));
+    if (fuse_norm) v = v / 255.0f - 0.5f;
+    return v;
+  };
+  float* dst = out + (long)b * c * hw + i * h + j;
+  if (staged) {
+    const uint8_t* l = reinterpret_cast<const uint8_t*>(aug_lds);
+    const int o00 = (sy0 - sy_lo) * h + sx0, o01 = (sy0 - sy_lo) * h + sx1;
+    const int o10 = (sy1 - sy_lo) * h + sx0, o11 = (sy1 - sy_lo) * h + sx1;
+    for (int ch = 0; ch < c; ++ch) {
+      const uint8_t* s = l + ch * NR * h;
+      dst[(long)ch * hw] = blend((float)s[o00], (float)s[o01], (float)s[o10], (float)s[o11]);
+    }
+  } else {
+    const int o00 = sy0 * h + sx0, o01 = sy0 * h + sx1, o10 = sy1 * h + sx0, o11 = sy1 * h + sx1;
+    for (int ch = 0; ch < c; ++ch) {
+      const uint8_t* s = src + (long)ch * hw;
+      dst[(long)ch * hw] = blend((float)s[o00], (float)s[o01], (float)s[o10], (float)s[o11]);
+    }
+  }
+}
+
+// rows-in-LDS launch when the frame layout allows it (dword rows); returns false when it does not
+bool launch_aug_rows(const uint8_t* obs, const float* shift, const uint8_t* obs1, const float* shift1,
+                     const float* base, float* out, int n, int c, int h, int pad, int fuse_norm, hipStream_t st) {
+  static const bool off = getenv("DRQ_AUG_VARIANT") && atoi(getenv("DRQ_AUG_VARIANT")) == 0;   // development knob
+  if (off || h % 4 != 0 || h > 256 || n > 65535 || ((uintptr_t)obs & 3) || (obs1 && ((uintptr_t)obs1 & 3))) return false;
+  const int R = 256 / h, NR = R + 2;
+  const size_t lds = (size_t)c * NR * h;
+  if (R < 1 || lds > 64 * 1024) return false;
+  hipLaunchKernelGGL(aug_rows_kernel, dim3((unsigned)((h + R - 1) / R), (unsigned)n, obs1 ? 2 : 1), dim3(256), lds, st,
+                     obs, shift, base, out, n, c, h, pad, fuse_norm, obs1, shift1, R, NR);
+  return true;
+}
+
 // ------------------------------------------------------------------------------------------------
 // LayerNorm + tanh.  One wave per row, F <= 256.
 // ------------------------------------------------------------------------------------------------
@@ -920,6 +1023,10 @@ int drq_ln_tanh_bwd_part(const float* dh0, int ld0, const float* dh1, int ld1, c
 int drq_aug_fwd(const uint8_t* obs, const float* shift_xy, const float* base_grid, float* out, int n, int c,
                 int hw, int pad, int fuse_norm, hipStream_t st) {
   if (!obs || !shift_xy || !base_grid || !out || n <= 0 || c <= 0 || hw <= 0 || pad < 0) return DRQ_EARG;
+  if (launch_aug_rows(obs, shift_xy, nullptr, nullptr, base_grid, out, n, c, hw, pad, fuse_norm, st)) {
+    DRQ_LAUNCH_CHECK();
+    return DRQ_OK;
+  }
   const long total = (long)n * hw * hw;
   hipLaunchKernelGGL(aug_kernel<uint8_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, obs, shift_xy,
                      base_grid, out, n, c, hw, pad, fuse_norm);
@@ -932,6 +1039,10 @@ int drq_aug_fwd_pair(const uint8_t* obs, const float* shift, const uint8_t* obs1
                      const float* base_grid, float* out, int n, int c, int hw, int pad, int fuse_norm, hipStream_t st) {
   if (!obs || !shift || !obs1 || !shift1 || !base_grid || !out || n <= 0 || c <= 0 || hw <= 0 || pad < 0)
     return DRQ_EARG;
+  if (launch_aug_rows(obs, shift, obs1, shift1, base_grid, out, n, c, hw, pad, fuse_norm, st)) {
+    DRQ_LAUNCH_CHECK();
+    return DRQ_OK;
+  }
   const long total = (long)n * hw * hw;
   hipLaunchKernelGGL(aug_kernel<uint8_t>, dim3((unsigned)((total + 255) / 256), 2), dim3(256), 0, st, obs, shift,
                      base_grid, out, n, c, hw, pad, fuse_norm, obs1, shift1);
