@@ -15,6 +15,16 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // obs1/shift1 (optional): a second set of n frames handled by blockIdx.y == 1, written behind the first n frames of
 // out (the update augments obs and next_obs with independent shifts: one launch for both)
+// v / 255 correctly rounded (v >= 0, normal range) in three instructions instead of the IEEE division sequence:
+// q = v*r, e = v - 255 q (exact), q' = q + e*r with r = RN(1/255).  tools/check_div255.py checks every float32
+// mantissa against the exactly rounded quotient (the identity is scale invariant).
+__device__ __forceinline__ float div255(float v) {
+  const float r = 1.0f / 255.0f;
+  const float q = __fmul_rn(v, r);
+  const float e = __fmaf_rn(-q, 255.0f, v);
+  return __fmaf_rn(e, r, q);
+}
+
 template <typename T>
 __global__ void aug_kernel(const T* __restrict__ obs, const float* __restrict__ shift,
                            const float* __restrict__ base, float* __restrict__ out, int n, int c, int h,
@@ -60,7 +70,7 @@ __global__ void aug_kernel(const T* __restrict__ obs, const float* __restrict__ 
     if (k01) v = __fadd_rn(v, __fmul_rn(t01, w01));
     if (k10) v = __fadd_rn(v, __fmul_rn(t10, w10));
     if (k11) v = __fadd_rn(v, __fmul_rn(t11, w11));
-    if (fuse_norm) v = v / 255.0f - 0.5f;
+    if (fuse_norm) v = __fsub_rn(div255(v), 0.5f);
     return v;
   };
   if (c == 9) {          // frame_stack 3 (cfgs/config.yaml:7): all 36 tap loads in flight together
@@ -122,12 +132,22 @@ __global__ __launch_bounds__(256) void aug_rows_kernel(const uint8_t* __restrict
   const bool staged = nrows >= 1 && nrows <= NR;
   const uint8_t* src = obs + (long)b * c * hw;
   if (staged) {
-    const int per_ch = nrows * hq;
-    for (int idx = threadIdx.x; idx < c * per_ch; idx += 256) {
-      const int ch = idx / per_ch, rem = idx - ch * per_ch;
-      const int r = rem / hq, q = rem - r * hq;
-      aug_lds[(ch * NR + r) * hq + q] =
-          reinterpret_cast<const unsigned*>(src + (long)ch * hw + (long)(sy_lo + r) * h)[q];
+    // thread -> (row slot, dword of the row); row slots walk the (channel, row) pairs without a division per step
+    const int rs = threadIdx.x / hq, q = threadIdx.x - rs * hq;
+    const int nslots = 256 / hq;
+    if (rs < nslots) {
+      const int step_ch = nslots / nrows, step_r = nslots - step_ch * nrows;
+      int ch = rs / nrows, r = rs - ch * nrows;
+      while (ch < c) {
+        aug_lds[(ch * NR + r) * hq + q] =
+            reinterpret_cast<const unsigned*>(src + (long)ch * hw + (long)(sy_lo + r) * h)[q];
+        r += step_r;
+        ch += step_ch;
+        if (r >= nrows) {
+          r -= nrows;
+          ++ch;
+        }
+      }
     }
   }
   __syncthreads();
@@ -150,7 +170,7 @@ __global__ __launch_bounds__(256) void aug_rows_kernel(const uint8_t* __restrict
     if (k01) v = __fadd_rn(v, __fmul_rn(t01, w01));
     if (k10) v = __fadd_rn(v, __fmul_rn(t10, w10));
     if (k11) v = __fadd_rn(v, __fmul_rn(t11, w11));
-    if (fuse_norm) v = v / 255.0f - 0.5f;
+    if (fuse_norm) v = __fsub_rn(div255(v), 0.5f);
     return v;
   };
   float* dst = out + (long)b * c * hw + i * h + j;

@@ -57,6 +57,17 @@ def test_aug_vs_oracle_and_reference(ops):
         assert torch.equal(out_n, out / 255.0 - 0.5)
 
 
+def test_aug_fused_normalisation_equals_true_division(ops):
+    """obs / 255.0 - 0.5 (drqv2.py:54) fused into the augmentation: the kernel's division-free sequence must give
+    the correctly rounded quotient on every value a training batch produces (uint8 and float entry, both kernels)."""
+    obs = synth.make_batch(64, 1, 9, seed=21, smooth=False)[0]
+    sh = torch.from_numpy(np.random.RandomState(5).randint(0, 9, (64, 2))).float()
+    out = ops.random_shifts_aug(obs.cuda(), sh.cuda(), 4).cpu()
+    out_n = ops.random_shifts_aug(obs.cuda(), sh.cuda(), 4, fuse_norm=True).cpu()
+    assert torch.equal(out_n, out / 255.0 - 0.5)
+    assert torch.equal(ops.random_shifts_aug(obs.float().cuda(), sh.cuda(), 4).cpu(), out)
+
+
 def test_aug_shift_indices_bit_exact_all_81(ops):
     """every (sx,sy) in [0,8]^2: the output is the integer crop up to fp32 dust -> rounding recovers
     the exact uint8 crop, i.e. the shift the kernel applied is the shift that was drawn."""
