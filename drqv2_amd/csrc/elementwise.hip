@@ -65,11 +65,15 @@ __global__ void aug_kernel(const T* __restrict__ obs, const float* __restrict__ 
   const int o00 = sy0 * h + sx0, o01 = sy0 * h + sx1, o10 = sy1 * h + sx0, o11 = sy1 * h + sx1;
   const bool k00 = okx0 && oky0, k01 = okx1 && oky0, k10 = okx0 && oky1, k11 = okx1 && oky1;
   auto blend = [&](float t00, float t01, float t10, float t11) {
+    // each product is rounded on its own (torch's grid_sample does not fuse them): the empty asm keeps hipcc from
+    // contracting a product into the following add, which the contract(off) pragma does not prevent in a lambda
+    float p0 = t00 * w00, p1 = t01 * w01, p2 = t10 * w10, p3 = t11 * w11;
+    asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
     float v = 0.f;
-    if (k00) v = __fadd_rn(v, __fmul_rn(t00, w00));
-    if (k01) v = __fadd_rn(v, __fmul_rn(t01, w01));
-    if (k10) v = __fadd_rn(v, __fmul_rn(t10, w10));
-    if (k11) v = __fadd_rn(v, __fmul_rn(t11, w11));
+    if (k00) v = v + p0;
+    if (k01) v = v + p1;
+    if (k10) v = v + p2;
+    if (k11) v = v + p3;
     if (fuse_norm) v = __fsub_rn(div255(v), 0.5f);
     return v;
   };
@@ -159,17 +163,21 @@ __global__ __launch_bounds__(256) void aug_rows_kernel(const uint8_t* __restrict
   const int x0 = (int)fx, y0 = (int)fy;
   const float wx1 = ix - fx, wx0 = (fx + 1.f) - ix;
   const float wy1 = iy - fy, wy0 = (fy + 1.f) - iy;
-  const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;   // nw, ne, sw, se
   const bool okx0 = x0 >= 0 && x0 < S, okx1 = x0 + 1 >= 0 && x0 + 1 < S;
   const bool oky0 = y0 >= 0 && y0 < S, oky1 = y0 + 1 >= 0 && y0 + 1 < S;
   const int sx0 = cl(x0), sx1 = cl(x0 + 1), sy0 = cl(y0), sy1 = cl(y0 + 1);
-  const bool k00 = okx0 && oky0, k01 = okx1 && oky0, k10 = okx0 && oky1, k11 = okx1 && oky1;
+  // a tap outside the padded frame is skipped by aug_kernel; here it gets weight +0 (t >= 0, so the sum is
+  // unchanged bit for bit), and the first add of aug_kernel is 0 + x = x: no selects and one add less per channel
+  const float w00 = okx0 && oky0 ? wx0 * wy0 : 0.f, w01 = okx1 && oky0 ? wx1 * wy0 : 0.f;     // nw, ne
+  const float w10 = okx0 && oky1 ? wx0 * wy1 : 0.f, w11 = okx1 && oky1 ? wx1 * wy1 : 0.f;     // sw, se
   auto blend = [&](float t00, float t01, float t10, float t11) {
-    float v = 0.f;
-    if (k00) v = __fadd_rn(v, __fmul_rn(t00, w00));
-    if (k01) v = __fadd_rn(v, __fmul_rn(t01, w01));
-    if (k10) v = __fadd_rn(v, __fmul_rn(t10, w10));
-    if (k11) v = __fadd_rn(v, __fmul_rn(t11, w11));
+    // each product is rounded on its own: the empty asm keeps hipcc from contracting it into the following add
+    // (the contract(off) pragma is not honoured inside this lambda once the selects around the adds are gone)
+    float p0 = t00 * w00, p1 = t01 * w01, p2 = t10 * w10, p3 = t11 * w11;
+    asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+    float v = p0 + p1;
+    v = v + p2;
+    v = v + p3;
     if (fuse_norm) v = __fsub_rn(div255(v), 0.5f);
     return v;
   };
