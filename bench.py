@@ -148,6 +148,7 @@ def main():
         "metric": "agent updates/sec (batch=256, 9x84x84 obs)", "value": value, "unit": "updates/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "ms_per_step_p10_p50_p90": [pct(0.1), pct(0.5), pct(0.9)],
+        "ms_per_step_max": per[-1] if per else None,
         "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic" + (" (batch copied host->device every update)" if args.host_batch else "")
                                 + (" (batches assembled by the device replay)" if args.device_replay else ""),

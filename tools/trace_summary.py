@@ -1,7 +1,7 @@
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 names = [r['Kernel_Name'] for r in rows]
-idx = [i for i, n in enumerate(names) if 'aug_kernel' in n]
+idx = [i for i, n in enumerate(names) if 'aug_kernel' in n or 'aug_rows_kernel' in n]
 s, e = idx[-3], idx[-2]          # the last complete update (one aug launch per update)
 t0 = int(rows[s]['Start_Timestamp']); prev = t0
 agg = collections.OrderedDict()
