@@ -62,17 +62,20 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, int batch, int
 // mask is applied when the tile is written to LDS (store_tile).  A load behind a per-lane branch, or a
 // select right after it, makes the compiler wait for it at once and serialises the register queue.
 // Requires rows >= 1 and kend > kbeg (checked by the caller).
-template <int BR, bool KC, bool V4, int BK>
+// FULL: every tile of the launch lies inside the matrix (no clamps here, no selects in store_tile: a select is a
+// VALU instruction per staged element, and VALU work between MFMAs costs matrix-pipe cycles -- DESIGN.md section 3)
+template <int BR, bool KC, bool V4, int BK, bool FULL = false>
 __device__ __forceinline__ void load_tile(const float* P, long ld, int row0, int rows, int k0, int kend,
                                           float (&reg)[BR * BK / 256], int tid) {
   if constexpr (KC && V4) {
     // BK/4 threads x float4 along k per row, 1024/BK rows per pass (kend % 4 == 0, kend >= 4)
     constexpr int TPR = BK / 4, RPP = 256 / TPR;
     const int r = tid / TPR, kq = (tid % TPR) * 4;
-    const int kc = min(k0 + kq, kend - 4);
+    const int kc = FULL ? k0 + kq : min(k0 + kq, kend - 4);
 #pragma unroll
     for (int p = 0; p < BR / RPP; ++p) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(P + (long)min(row0 + p * RPP + r, rows - 1) * ld + kc);
+      const int row = FULL ? row0 + p * RPP + r : min(row0 + p * RPP + r, rows - 1);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(P + (long)row * ld + kc);
       reg[p * 4 + 0] = v[0]; reg[p * 4 + 1] = v[1]; reg[p * 4 + 2] = v[2]; reg[p * 4 + 3] = v[3];
     }
   } else if constexpr (KC) {
@@ -93,17 +96,17 @@ __device__ __forceinline__ void load_tile(const float* P, long ld, int row0, int
 }
 
 // registers -> LDS [row][k] (pitch PK), zeroing what lies outside the matrix
-template <int BR, bool KC, bool V4, int BK>
+template <int BR, bool KC, bool V4, int BK, bool FULL = false>
 __device__ __forceinline__ void store_tile(float* S, const float (&reg)[BR * BK / 256], int row0, int rows, int k0,
                                            int kend, int tid) {
   constexpr int PK = BK + 2;
   if constexpr (KC && V4) {
     constexpr int TPR = BK / 4, RPP = 256 / TPR;
     const int r = tid / TPR, kq = (tid % TPR) * 4;
-    const bool kok = k0 + kq < kend;
+    const bool kok = FULL || k0 + kq < kend;
 #pragma unroll
     for (int p = 0; p < BR / RPP; ++p) {
-      const bool ok = kok && row0 + p * RPP + r < rows;
+      const bool ok = FULL || (kok && row0 + p * RPP + r < rows);
       float* d = S + (p * RPP + r) * PK + kq;
       d[0] = ok ? reg[p * 4 + 0] : 0.f; d[1] = ok ? reg[p * 4 + 1] : 0.f;
       d[2] = ok ? reg[p * 4 + 2] : 0.f; d[3] = ok ? reg[p * 4 + 3] : 0.f;
@@ -139,7 +142,7 @@ __device__ __forceinline__ float tile_rowsum(const float (&reg)[BR * BK / 256], 
   return s;
 }
 
-template <int TM, int TN, bool A_KC, bool B_KC, bool V4, int BK = BK0>
+template <int TM, int TN, bool A_KC, bool B_KC, bool V4, int BK = BK0, bool FULL = false>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   constexpr int PK = BK + 2;      // LDS pitch: bank = 2*row + k, conflict-free MFMA operand reads
   constexpr int BM = 32 * TM, BN = 32 * TN;
@@ -176,8 +179,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   // tile t lives in register slot t % D until it is written to LDS buffer t & 1 during step t-1
   auto fetch = [&](int t, float (&fa)[RA], float (&fb)[RB]) {
     const int tc = t < nsteps ? t : nsteps - 1;   // past the end: harmless re-load, never written to LDS
-    load_tile<BM, A_KC, V4, BK>(A, g.lda, m0, g.M, kbeg + tc * BK, kend, fa, tid);
-    load_tile<BN, B_KC, V4, BK>(B, g.ldb, n0, g.N, kbeg + tc * BK, kend, fb, tid);
+    load_tile<BM, A_KC, V4, BK, FULL>(A, g.lda, m0, g.M, kbeg + tc * BK, kend, fa, tid);
+    load_tile<BN, B_KC, V4, BK, FULL>(B, g.ldb, n0, g.N, kbeg + tc * BK, kend, fb, tid);
   };
   // fused bias gradient of a wgrad GEMM: the workgroups of the first column tile also sum their A rows over k
   bool do_rs = false;
@@ -187,8 +190,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     fetch(0, ra[0], rb[0]);
     if constexpr (!A_KC)
       if (do_rs) rs += tile_rowsum<BM, BK>(ra[0], m0, g.M, kbeg, kend, tid);
-    store_tile<BM, A_KC, V4, BK>(As[0], ra[0], m0, g.M, kbeg, kend, tid);
-    store_tile<BN, B_KC, V4, BK>(Bs[0], rb[0], n0, g.N, kbeg, kend, tid);
+    store_tile<BM, A_KC, V4, BK, FULL>(As[0], ra[0], m0, g.M, kbeg, kend, tid);
+    store_tile<BN, B_KC, V4, BK, FULL>(Bs[0], rb[0], n0, g.N, kbeg, kend, tid);
 #pragma unroll
     for (int d = 1; d <= D; ++d) fetch(d, ra[d % D], rb[d % D]);
   }
@@ -219,8 +222,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
     if constexpr (!A_KC)
       if (do_rs) rs += tile_rowsum<BM, BK>(ra[(s + 1) % D], m0, g.M, kbeg + (t + 1) * BK, kend, tid);
-    store_tile<BM, A_KC, V4, BK>(As[(s + 1) & 1], ra[(s + 1) % D], m0, g.M, kbeg + (t + 1) * BK, kend, tid);
-    store_tile<BN, B_KC, V4, BK>(Bs[(s + 1) & 1], rb[(s + 1) % D], n0, g.N, kbeg + (t + 1) * BK, kend, tid);
+    store_tile<BM, A_KC, V4, BK, FULL>(As[(s + 1) & 1], ra[(s + 1) % D], m0, g.M, kbeg + (t + 1) * BK, kend, tid);
+    store_tile<BN, B_KC, V4, BK, FULL>(Bs[(s + 1) & 1], rb[(s + 1) % D], n0, g.N, kbeg + (t + 1) * BK, kend, tid);
     fetch(t + 1 + D, ra[(s + 1) % D], rb[(s + 1) % D]);
     __syncthreads();
   };
@@ -353,6 +356,13 @@ template <int TM, int TN, bool A_KC, bool B_KC, bool V4, int BK = BK0>
 int launch(const GemmArgs& g, hipStream_t st) {
   constexpr int BM = 32 * TM, BN = 32 * TN;
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.nbatch * g.splitk);
+  // the forward form of the hidden layers (all dimensions multiples of the tiles): the variant without masks
+  constexpr bool HAS_FULL = TM == 1 && TN == 1 && A_KC && B_KC && V4 && BK == BK0;
+  const bool full = g.M % BM == 0 && g.N % BN == 0 && g.K % BK == 0 && g.kchunk % BK == 0;
+  if constexpr (HAS_FULL) {
+    if (full) hipLaunchKernelGGL((gemm_kernel<TM, TN, A_KC, B_KC, V4, BK, true>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_kernel<TM, TN, A_KC, B_KC, V4, BK>), grid, dim3(256), 0, st, g);
+  } else
   hipLaunchKernelGGL((gemm_kernel<TM, TN, A_KC, B_KC, V4, BK>), grid, dim3(256), 0, st, g);
   DRQ_LAUNCH_CHECK();
   g_last_splitk = g.splitk;
