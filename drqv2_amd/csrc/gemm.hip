@@ -75,7 +75,16 @@ __device__ __forceinline__ void load_tile(const float* P, long ld, int row0, int
 #pragma unroll
     for (int p = 0; p < BR / RPP; ++p) {
       const int row = FULL ? row0 + p * RPP + r : min(row0 + p * RPP + r, rows - 1);
-      const f32x4 v = *reinterpret_cast<const f32x4*>(P + (long)row * ld + kc);
+      f32x4 v;
+      if constexpr (FULL) {
+        // uniform base (advances with k0: scalar) + loop-invariant 32-bit lane offset: no address VALU per tile
+        // (a buffer load: with a plain pointer hipcc adds k0 to a per-lane 64-bit address on the VALU every tile)
+        const unsigned voff = (unsigned)(((long)row * ld + kq) * 4);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)P, 0, 0xffffffffu, 0x00020000);
+        v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (unsigned)k0 * 4u, 0));
+      } else {
+        v = *reinterpret_cast<const f32x4*>(P + (long)row * ld + kc);
+      }
       reg[p * 4 + 0] = v[0]; reg[p * 4 + 1] = v[1]; reg[p * 4 + 2] = v[2]; reg[p * 4 + 3] = v[3];
     }
   } else if constexpr (KC) {
