@@ -335,14 +335,20 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(WgradArgs a) {
   constexpr int HOUT = G::HOUT, KS = G::KS, XP = G::XP, DP = G::DP, NT = G::NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63;
-  const int wid = threadIdx.x >> 6;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row bookkeeping stays scalar
   const int col = lane & 31;
   const int half = lane >> 5;
   float* xs = smem + wid * G::WAVE_LDS;
   float* ds = xs + G::XS;
 
   // zero the wave-private tile once: pad columns must hold finite values (they meet dY == 0)
-  for (int i = lane; i < G::WAVE_LDS; i += 64) xs[i] = 0.f;
+  if constexpr (G::WAVE_LDS % 4 == 0) {
+    float4* x4 = reinterpret_cast<float4*>(xs);
+#pragma unroll 4
+    for (int i = lane; i < G::WAVE_LDS / 4; i += 64) x4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+    for (int i = lane; i < G::WAVE_LDS; i += 64) xs[i] = 0.f;
+  }
 
   // this lane's operand base addresses (floats)
   int bbase;   // B operand: X[pixel][column]
@@ -362,10 +368,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(WgradArgs a) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float bsum = 0.f;
 
-  const long units = (long)a.nb * HOUT;       // (sample, output row)
-  const long nw = (long)gridDim.x * 4;
-  const long gw = (long)blockIdx.x * 4 + wid;
-  const long u0 = units * gw / nw, u1 = units * (gw + 1) / nw;
+  // (sample, output row) units split evenly over the waves, the first `rem` waves take one more (all scalar)
+  const int units = a.nb * HOUT;
+  const int nw = (int)gridDim.x * 4;
+  const int gw = (int)blockIdx.x * 4 + wid;
+  const int per = units / nw, rem = units - per * nw;
+  const int u0 = gw * per + (gw < rem ? gw : rem);
+  const int u1 = u0 + per + (gw < rem ? 1 : 0);
 
   // ---- register staging with 8-byte pieces: lane = (row within the instruction, pair within the row)
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
@@ -377,29 +386,37 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(WgradArgs a) {
   const int dg_lane = (int)(dr * a.dy_cs + 2 * dpr) * 4;
   const int xl_lane = xr * XP + 2 * xpr;                             // LDS float offsets (lane part)
   const int dl_lane = dr * DP + 2 * dpr;
-  const bool d_last_odd = (HOUT & 1) && dpr == G::DPAIRS - 1;        // second float of the pair is column HOUT
-
   u32x2 rx[3 * G::XJ], rd[G::DJ];
-  auto issue_loads = [&](long u) {
-    const int b = (int)(u / HOUT);
-    const int oy = (int)(u - (long)b * HOUT);
+  // per-lane offsets are loop invariants (a disabled lane sits far out of the buffer's range and stays there when
+  // the wave-uniform row offset is added: 0x7ffffff0 + offset < 2^32); only the last piece of a row group is partial
+  const int xv_full = xact ? xg_lane : 0x7ffffff0;
+  const int xv_last = xact && (G::XJ - 1) * G::XRPI + xr < CIN ? xg_lane : 0x7ffffff0;
+  const int dv_full = dact ? dg_lane : 0x7ffffff0;
+  const int dv_last = dact && (G::DJ - 1) * G::DRPI + dr < 32 ? dg_lane : 0x7ffffff0;
+  auto issue_loads = [&](int u) {
+    const int b = u / HOUT;
+    const int oy = u - b * HOUT;
     const int xbase = ((b * CIN * HIN + oy * STRIDE) * HIN) * 4;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
       for (int j = 0; j < G::XJ; ++j) {
-        // rows (ky, ci = j*XRPI + xr); lanes past the last channel or the last row of the instruction are
-        // sent out of range (descriptor returns 0, nothing is written for them)
-        const bool ok = xact && j * G::XRPI + xr < CIN;
-        const int voff = ok ? xbase + xg_lane : 0x7ffffff0;
-        rx[ky * G::XJ + j] = __builtin_amdgcn_raw_buffer_load_b64(xrsrc, voff, (j * G::XRPI * HIN * HIN + ky * HIN) * 4, 0);
+        // rows (ky, ci = j*XRPI + xr)
+        const int xv = j == G::XJ - 1 ? xv_last : xv_full;
+        const int row_off = (j * G::XRPI * HIN * HIN + ky * HIN) * 4;
+        if constexpr (HIN % 2 == 0) {
+          // even rows: no 8-byte piece reaches past its row, so the uniform part may ride in the scalar offset
+          // (which the range check does not see) and the load needs no VALU instruction at all
+          rx[ky * G::XJ + j] = __builtin_amdgcn_raw_buffer_load_b64(xrsrc, xv, xbase + row_off, 0);
+        } else {
+          rx[ky * G::XJ + j] = __builtin_amdgcn_raw_buffer_load_b64(xrsrc, xv + xbase, row_off, 0);
+        }
       }
     const int dbase = (int)(a.dy_off + (long)b * a.dy_bs + (long)oy * a.dy_rs) * 4;
 #pragma unroll
     for (int j = 0; j < G::DJ; ++j) {
-      const bool ok = dact && j * G::DRPI + dr < 32;
-      const int voff = ok ? dbase + dg_lane + (int)(j * G::DRPI * a.dy_cs) * 4 : 0x7ffffff0;
-      rd[j] = __builtin_amdgcn_raw_buffer_load_b64(drsrc, voff, 0, 0);
+      const int dv = j == G::DJ - 1 ? dv_last : dv_full;
+      rd[j] = __builtin_amdgcn_raw_buffer_load_b64(drsrc, dv + (dbase + (int)(j * G::DRPI * a.dy_cs) * 4), 0, 0);
     }
   };
   auto write_lds = [&]() {
@@ -411,21 +428,20 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(WgradArgs a) {
           *reinterpret_cast<u32x2*>(xs + (ky * CIN + j * G::XRPI) * XP + xl_lane) = rx[ky * G::XJ + j];
 #pragma unroll
     for (int j = 0; j < G::DJ; ++j)
-      if (dact && j * G::DRPI + dr < 32) {
-        u32x2 v = rd[j];
-        if (d_last_odd) v[1] = 0u;      // column HOUT of an odd row must stay zero (it pairs with the pad pixel)
-        *reinterpret_cast<u32x2*>(ds + j * G::DRPI * DP + dl_lane) = v;
-      }
+      if (dact && j * G::DRPI + dr < 32)
+        *reinterpret_cast<u32x2*>(ds + j * G::DRPI * DP + dl_lane) = rd[j];
   };
 
   if (u0 < u1) issue_loads(u0);
-  for (long u = u0; u < u1; ++u) {
+  for (int u = u0; u < u1; ++u) {
     // (single wave: LDS operations of one wave complete in order, no barrier needed)
     write_lds();
     if (u + 1 < u1) issue_loads(u + 1);   // in flight under the MFMA loop below
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      const float av = ds[abase + 2 * s];
+      float av = ds[abase + 2 * s];
+      // an odd row's last pixel pair is (HOUT-1, pad): the pad's dY (the next row's first value in LDS) is zero
+      if ((HOUT & 1) && s == KS - 1) av = half ? 0.f : av;
       bsum += av;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
