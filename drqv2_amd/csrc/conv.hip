@@ -329,8 +329,10 @@ struct WgradGeom {
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-template <int CIN, int HIN, int STRIDE>
-__global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(WgradArgs a) {
+unsigned long long* g_wgrad1_stamps = nullptr;   // set by drq_dev_wgrad1_stamps (undeclared development hook)
+
+template <int CIN, int HIN, int STRIDE, bool STAMP = false>
+__global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(WgradArgs a, unsigned long long* stamps = nullptr) {
   using G = WgradGeom<CIN, HIN, STRIDE>;
   constexpr int HOUT = G::HOUT, KS = G::KS, XP = G::XP, DP = G::DP, NT = G::NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -340,6 +342,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(WgradArgs a) {
   const int half = lane >> 5;
   float* xs = smem + wid * G::WAVE_LDS;
   float* ds = xs + G::XS;
+  unsigned long long* stamp = nullptr;            // development only: 32 per wave; [30], [29] = wall clock start / end
+  int nstamp = 0;
+  if (STAMP) {
+    stamp = stamps + ((size_t)blockIdx.x * 4 + wid) * 32;
+    if (lane == 0) stamp[30] = __builtin_amdgcn_s_memrealtime();
+  }
+  auto mark = [&]() {
+    if (STAMP) {
+      if (nstamp < 28 && lane == 0) stamp[nstamp] = __builtin_amdgcn_s_memtime();
+      ++nstamp;
+    }
+  };
+  mark();
 
   // zero the wave-private tile once: pad columns must hold finite values (they meet dY == 0)
   if constexpr (G::WAVE_LDS % 4 == 0) {
@@ -433,9 +448,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(WgradArgs a) {
   };
 
   if (u0 < u1) issue_loads(u0);
+  mark();
   for (int u = u0; u < u1; ++u) {
+    mark();
     // (single wave: LDS operations of one wave complete in order, no barrier needed)
     write_lds();
+    if (STAMP) {                          // odd stamps: the staged row is in LDS (loads waited for, stores issued)
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+      mark();
+    }
     if (u + 1 < u1) issue_loads(u + 1);   // in flight under the MFMA loop below
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -454,7 +475,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(WgradArgs a) {
   }
 
   // ---- reduce the 4 waves of the block through LDS, one partial record per block
+  mark();
   __syncthreads();
+  mark();
   float* red = smem;   // [4][PART]  (fits: checked on the host)
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -465,6 +488,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(WgradArgs a) {
   float* out = a.part + (long)blockIdx.x * G::PART;
   for (int i = threadIdx.x; i < G::PART; i += 256)
     out[i] = (red[i] + red[G::PART + i]) + (red[2 * G::PART + i] + red[3 * G::PART + i]);
+  mark();
+  if (STAMP && lane == 0) {
+    stamp[29] = __builtin_amdgcn_s_memrealtime();
+    stamp[28] = (unsigned long long)nstamp;
+  }
 }
 
 // ---- wgrad v2: the four waves of a workgroup take four consecutive output rows of one sample and SHARE
@@ -1109,9 +1137,14 @@ int launch_wgrad(const WgradArgs& a0, float* dw, float* db, float* ws, size_t ws
   if (v2)
     hipLaunchKernelGGL((conv3x3_wgrad2_kernel<CIN, HIN, STRIDE>), dim3((unsigned)blocks), dim3(256), lds_floats * 4,
                        st, a);
-  else
+  else if (CIN == 9 && g_wgrad1_stamps) {
+    (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel<9, 84, 2, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_floats * 4);
+    hipLaunchKernelGGL((conv3x3_wgrad_kernel<9, 84, 2, true>), dim3((unsigned)blocks), dim3(256), lds_floats * 4, st, a,
+                       g_wgrad1_stamps);
+  } else
     hipLaunchKernelGGL((conv3x3_wgrad_kernel<CIN, HIN, STRIDE>), dim3((unsigned)blocks), dim3(256), lds_floats * 4,
-                       st, a);
+                       st, a, (unsigned long long*)nullptr);
   DRQ_LAUNCH_CHECK();
   if (nblocks_out) *nblocks_out = (int)blocks;
   if (defer) return DRQ_OK;
@@ -1167,6 +1200,7 @@ extern "C" {
 // development hook (not part of the ABI): device buffer of 32 u64 per wave for DRQ_CONV_VARIANT=10
 void drq_dev_conv_stamps(void* p) { g_conv_stamps = (unsigned long long*)p; }
 void drq_dev_wgrad_stamps(void* p) { g_wgrad_stamps = (unsigned long long*)p; }
+void drq_dev_wgrad1_stamps(void* p) { g_wgrad1_stamps = (unsigned long long*)p; }
 void drq_dev_conv_variant(int v) { g_conv_variant = v; }
 
 // y = relu?(conv3x3(x, w) + bias); x [nb][cin][hin][hin], y written with the given strides.
