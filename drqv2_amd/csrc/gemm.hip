@@ -486,7 +486,8 @@ int drq_gemm_batched_partial(int nbatch, const float* const* A, long lda, int a_
                              int b_kc, float* const* C, long ldc, int M, int N, int K, const float* const* bias,
                              float* ws, size_t ws_bytes, int* splitk_out, hipStream_t st) {
   // the trunk forward (k-contiguous operands, N <= 64, long K) has its own kernel
-  if (a_kc && b_kc && N <= 64 && K >= 4096 && ldc == N && !getenv("DRQ_NO_TRUNK_KERNEL")) {
+  static const bool no_trunk = getenv("DRQ_NO_TRUNK_KERNEL") != nullptr;     // development knob (A/B against the tiled GEMM)
+  if (a_kc && b_kc && N <= 64 && K >= 4096 && ldc == N && !no_trunk) {
     int sk = 1;
     const int rc = drq_trunk_fwd_partial(nbatch, A, lda, B, ldb, M, N, K, ws, ws_bytes, &sk, st);
     if (rc == DRQ_OK) {

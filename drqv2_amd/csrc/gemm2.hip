@@ -423,8 +423,9 @@ int drq_trunk_fwd_partial(int nbatch, const float* const* A, long lda, const flo
   const int rows = tm2 ? M / 64 : M / 32;
   int blocks_k = (cus + nbatch * rows - 1) / (nbatch * rows);
   if (blocks_k * 4 > steps) blocks_k = steps / 4;
-  if (const char* e = getenv("DRQ_TRUNK_DBG")) {        // development knobs
-    const int d = atoi(e);
+  static const char* const dbg = getenv("DRQ_TRUNK_DBG");       // development knobs (read once)
+  if (dbg) {
+    const int d = atoi(dbg);
     if (d & 1) g.a_bytes = g.b_bytes = 0;               // every load out of range: MFMA time only
     if (d & 2) blocks_k *= 2;
   }
