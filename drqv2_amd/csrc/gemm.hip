@@ -429,7 +429,7 @@ int drq_gemm_batched_f32(int nbatch, const float* const* A, long lda, int a_kc, 
     if (rc != DRQ_EARG) return rc;
   }
   // the trunk layer's weight gradient (M = feature_dim, N = 39200, K = batch) likewise
-  if (nbatch == 1 && tile == 0 && splitk == 0 && scatter_hw == 0 && !a_kc && !b_kc && M <= 64 && N >= 4096 && !bias &&
+  if (nbatch == 1 && tile == 0 && splitk == 0 && scatter_hw == 0 && !a_kc && !b_kc && M <= 128 && N >= 4096 && !bias &&
       !relu && !aux) {
     const int rc = drq_trunk_wgrad(A[0], lda, B[0], ldb, C[0], ldc, M, N, K, rowsum ? rowsum[0] : nullptr, st);
     if (rc != DRQ_EARG) return rc;
@@ -487,7 +487,7 @@ int drq_gemm_batched_partial(int nbatch, const float* const* A, long lda, int a_
                              float* ws, size_t ws_bytes, int* splitk_out, hipStream_t st) {
   // the trunk forward (k-contiguous operands, N <= 64, long K) has its own kernel
   static const bool no_trunk = getenv("DRQ_NO_TRUNK_KERNEL") != nullptr;     // development knob (A/B against the tiled GEMM)
-  if (a_kc && b_kc && N <= 64 && K >= 4096 && ldc == N && !no_trunk) {
+  if (a_kc && b_kc && N <= 128 && K >= 4096 && ldc == N && !no_trunk) {
     int sk = 1;
     const int rc = drq_trunk_fwd_partial(nbatch, A, lda, B, ldb, M, N, K, ws, ws_bytes, &sk, st);
     if (rc == DRQ_OK) {

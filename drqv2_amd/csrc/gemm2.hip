@@ -184,8 +184,8 @@ int launch2(const G2Args& g, int nbatch, hipStream_t st) {
 }
 
 // ---- trunk forward: z = feat W^T with K = repr_dim (39200), N = feature_dim (50) (drqv2.py:71-72,91-92) --------
-// Both operands are k-contiguous and N fits two 32-column tiles, so a wave takes TM row tiles x both column tiles
-// and a slice of K: per 32-long k-step it loads 4*(TM+2) 16-byte pieces per lane for 32*TM MFMAs -- half (TM = 1)
+// Both operands are k-contiguous and N fits two 32-column tiles (four for feature_dim 100, with TM = 1), so a wave
+// takes TM row tiles x all column tiles and a slice of K: per 32-long k-step it loads 4*(TM+2) 16-byte pieces per lane for 32*TM MFMAs -- half (TM = 1)
 // or a third (TM = 2) of the loads per MFMA of the one-tile form above, which the texture addresser keeps up
 // with.  Weight rows >= N are out of the buffer's range and read as zero.  K is cut into gridDim.x slices
 // (whole k-steps, sizes differing by at most one step); the four waves of a workgroup sum their shares in wave
@@ -200,9 +200,9 @@ struct TrunkArgs {
   unsigned a_bytes, b_bytes;
 };
 
-template <int TM>
+template <int TM, int TN = 2>
 __global__ __launch_bounds__(256, 1) void trunk_fwd_kernel(TrunkArgs g) {
-  __shared__ float red[3 * TM * 2 * 16 * 64];
+  __shared__ float red[3 * TM * TN * 16 * 64];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col = lane & 31, half = lane >> 5;
@@ -220,37 +220,37 @@ __global__ __launch_bounds__(256, 1) void trunk_fwd_kernel(TrunkArgs g) {
   const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void*)g.A[batch], 0, g.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)g.B[batch], 0, g.b_bytes, 0x00020000);
   const unsigned lda4 = (unsigned)g.lda * 4, ldb4 = (unsigned)g.ldb * 4;
-  unsigned avoff[TM], bvoff[2];
+  unsigned avoff[TM], bvoff[TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i) avoff[i] = (unsigned)(m0 + i * 32 + col) * lda4 + (unsigned)(half * 4) * 4;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) bvoff[j] = (unsigned)(j * 32 + col) * ldb4 + (unsigned)(half * 4) * 4;
+  for (int j = 0; j < TN; ++j) bvoff[j] = (unsigned)(j * 32 + col) * ldb4 + (unsigned)(half * 4) * 4;
 
-  f32x16 acc[TM][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // two register stages (a third, i.e. loads issued two k-steps ahead, measured slower: 53.6 vs 51.4 us)
-  float a0[TM][16], b0[2][16], a1[TM][16], b1[2][16];
-  auto load = [&](float (&a)[TM][16], float (&b)[2][16], int s) {
+  float a0[TM][16], b0[TN][16], a1[TM][16], b1[TN][16];
+  auto load = [&](float (&a)[TM][16], float (&b)[TN][16], int s) {
     const int sc = s < ns ? s : ns - 1;                   // past the end: harmless re-load of the last step
     const unsigned so = (unsigned)(s0 + 4 * sc) * 128u;
 #pragma unroll
     for (int i = 0; i < TM; ++i) load_step<true>(a[i], ars, avoff[i], so, lda4);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) load_step<true>(b[j], brs, bvoff[j], so, ldb4);
+    for (int j = 0; j < TN; ++j) load_step<true>(b[j], brs, bvoff[j], so, ldb4);
   };
-  auto mfma_step = [&](const float (&a)[TM][16], const float (&b)[2][16]) {
+  auto mfma_step = [&](const float (&a)[TM][16], const float (&b)[TN][16]) {
 #pragma unroll
     for (int e = 0; e < 16; ++e)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
   };
   if (ns > 0) {
@@ -272,9 +272,9 @@ __global__ __launch_bounds__(256, 1) void trunk_fwd_kernel(TrunkArgs g) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[(((wid - 1) * TM + i) * 2 + j) * 1024 + r * 64 + lane] = acc[i][j][r];
+        for (int r = 0; r < 16; ++r) red[(((wid - 1) * TM + i) * TN + j) * 1024 + r * 64 + lane] = acc[i][j][r];
   }
   __syncthreads();
   if (wid > 0) return;
@@ -282,13 +282,13 @@ __global__ __launch_bounds__(256, 1) void trunk_fwd_kernel(TrunkArgs g) {
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < TN; ++j) {
       const int n = j * 32 + col;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = acc[i][j][r];
 #pragma unroll
-        for (int w = 0; w < 3; ++w) v += red[((w * TM + i) * 2 + j) * 1024 + r * 64 + lane];
+        for (int w = 0; w < 3; ++w) v += red[((w * TM + i) * TN + j) * 1024 + r * 64 + lane];
         if (n < g.N) out[(long)(m0 + i * 32 + rowmap2(r, half)) * g.N + n] = v;
       }
     }
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256, 1) void trunk_wgrad_kernel(TWArgs g) {
 // Returns DRQ_EARG when the problem is not eligible (the caller then uses the LDS-tiled kernel).
 int drq_trunk_wgrad(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K,
                     float* rowsum, hipStream_t st) {
-  if (M < 1 || M > 64 || N < 4096 || N % 32 || (K != 128 && K != 256)) return DRQ_EARG;
+  if (M < 1 || M > 128 || N < 4096 || N % 32 || (K != 128 && K != 256)) return DRQ_EARG;
   const size_t ab = (size_t)K * lda * 4, bb = (size_t)K * ldb * 4;
   if (ab >= (1ull << 31) || bb >= (1ull << 31)) return DRQ_EARG;
   TWArgs g{A, B, C, rowsum, lda, ldb, ldc, M, N, K, (unsigned)ab, (unsigned)bb};
@@ -404,7 +404,7 @@ int drq_trunk_wgrad(const float* A, long lda, const float* B, long ldb, float* C
 // Returns DRQ_EARG when the problem is not eligible (the caller then uses the LDS-tiled kernel).
 int drq_trunk_fwd_partial(int nbatch, const float* const* A, long lda, const float* const* B, long ldb, int M, int N,
                           int K, float* ws, size_t ws_bytes, int* splitk_out, hipStream_t st) {
-  if (nbatch <= 0 || nbatch > MAXB2 || M % 32 || M < 32 || N < 1 || N > 64 || K % 32 || K < 4096) return DRQ_EARG;
+  if (nbatch <= 0 || nbatch > MAXB2 || M % 32 || M < 32 || N < 1 || N > 128 || K % 32 || K < 4096) return DRQ_EARG;
   if (lda % 4 || ldb % 4 || !ws || ((uintptr_t)ws & 15)) return DRQ_EARG;
   const size_t ab = (size_t)M * lda * 4, bb = (size_t)N * ldb * 4;
   if (ab >= (1ull << 31) || bb >= (1ull << 31)) return DRQ_EARG;
@@ -419,7 +419,8 @@ int drq_trunk_fwd_partial(int nbatch, const float* const* A, long lda, const flo
   // four trunks of the critic update -- more concurrent row streams cost more in the memory system than the
   // extra waves hide
   const int steps = K / 32, cus = drq_num_cus();
-  const bool tm2 = M % 64 == 0 && (long)nbatch * (M / 32) * 4 >= 64;
+  const bool wide = N > 64;               // four column tiles per wave, one row tile
+  const bool tm2 = !wide && M % 64 == 0 && (long)nbatch * (M / 32) * 4 >= 64;
   const int rows = tm2 ? M / 64 : M / 32;
   int blocks_k = (cus + nbatch * rows - 1) / (nbatch * rows);
   if (blocks_k * 4 > steps) blocks_k = steps / 4;
@@ -432,7 +433,8 @@ int drq_trunk_fwd_partial(int nbatch, const float* const* A, long lda, const flo
   if (blocks_k < 2) return DRQ_EARG;      // a split count of 1 means "result in C" to the callers
   if ((size_t)nbatch * blocks_k * M * N * sizeof(float) > ws_bytes) return DRQ_EWS;
   const dim3 grid(blocks_k, rows, nbatch);
-  if (tm2) hipLaunchKernelGGL((trunk_fwd_kernel<2>), grid, dim3(256), 0, st, g);
+  if (wide) hipLaunchKernelGGL((trunk_fwd_kernel<1, 4>), grid, dim3(256), 0, st, g);
+  else if (tm2) hipLaunchKernelGGL((trunk_fwd_kernel<2>), grid, dim3(256), 0, st, g);
   else hipLaunchKernelGGL((trunk_fwd_kernel<1>), grid, dim3(256), 0, st, g);
   DRQ_LAUNCH_CHECK();
   if (splitk_out) *splitk_out = blocks_k;

@@ -218,7 +218,7 @@ def test_unsupported_shapes_are_refused(ops):
 @pytest.mark.parametrize("Brows,N,K,n", [(256, 1024, 1024, 2), (9, 50, 39200, 1), (31, 1024, 56, 2), (12, 6, 1024, 1),
                                          (40, 70, 33, 3), (256, 50, 39200, 1), (300, 100, 8192, 1), (5, 21, 4096, 1),
                                          (128, 50, 39200, 1), (256, 64, 4096, 1), (256, 33, 8192, 1),
-                                         (128, 1, 4128, 1)])
+                                         (128, 1, 4128, 1), (256, 100, 39200, 1), (128, 128, 4096, 1)])
 def test_gemm_batched_wgrad_with_fused_bias_grad(ops, Brows, N, K, n):
     """dW_i = dy_i^T x_i and db_i = column sums of dy_i from ONE launch, independent pointers per problem"""
     dys = [rnd(Brows, N, seed=10 + i) for i in range(n)]
@@ -295,7 +295,8 @@ def test_gemm_batched_forward_four_problems(ops):
 
 
 @pytest.mark.parametrize("M,N,K,n", [(256, 50, 39200, 4), (256, 50, 39200, 1), (64, 50, 4096, 2), (32, 64, 4128, 1),
-                                     (96, 7, 8192, 3), (512, 50, 39200, 1)])
+                                     (96, 7, 8192, 3), (512, 50, 39200, 1), (256, 100, 39200, 4), (32, 100, 39200, 1),
+                                     (64, 65, 4096, 2), (32, 128, 4096, 1)])
 def test_trunk_forward_partials(ops, M, N, K, n):
     """the trunk kernel (z = feat W^T, k-contiguous operands, N <= 64, long K): row tiles of 32 and 64, slices of
     unequal length, weight rows past N read as zero, one problem and several; the sum of its records is the GEMM."""
