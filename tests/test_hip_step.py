@@ -126,6 +126,12 @@ WIDE = {
                         updates=1, step0=0, smooth=True),
     "humanoid_b32": dict(C=9, A=21, F=100, H=1024, B=32, lr=8e-5, sched="linear(1.0,0.1,2000000)", wseed=5, bseed=50,
                          updates=1, step0=1000, smooth=True),
+    # the training shapes themselves (BASELINE configs[1] at batch 256, and the per-rank batch of a 2-GPU strong
+    # split): the trunk kernels (gemm2.hip: K = batch 128 / 256), the mask-free forward GEMM, full conv tile runs
+    "cheetah_b128": dict(C=9, A=6, F=50, H=1024, B=128, lr=1e-4, sched="linear(1.0,0.1,500000)", wseed=6, bseed=60,
+                         updates=1, step0=0, smooth=True),
+    "cheetah_b256": dict(C=9, A=6, F=50, H=1024, B=256, lr=1e-4, sched="linear(1.0,0.1,500000)", wseed=7, bseed=70,
+                         updates=1, step0=0, smooth=True),
 }
 
 
