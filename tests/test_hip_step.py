@@ -132,6 +132,10 @@ WIDE = {
                          updates=1, step0=0, smooth=True),
     "cheetah_b256": dict(C=9, A=6, F=50, H=1024, B=256, lr=1e-4, sched="linear(1.0,0.1,500000)", wseed=7, bseed=70,
                          updates=1, step0=0, smooth=True),
+    # feature_dim 100 (BASELINE configs[3]/[4] shapes): four column tiles per wave in the trunk forward, four row
+    # tiles in its weight gradient
+    "humanoid_b128": dict(C=9, A=21, F=100, H=1024, B=128, lr=8e-5, sched="linear(1.0,0.1,2000000)", wseed=8, bseed=80,
+                          updates=1, step0=1000, smooth=True),
 }
 
 
