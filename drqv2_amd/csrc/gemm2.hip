@@ -420,11 +420,12 @@ int drq_trunk_fwd_partial(int nbatch, const float* const* A, long lda, const flo
   // extra waves hide
   const int steps = K / 32, cus = drq_num_cus();
   const bool wide = N > 64;               // four column tiles per wave, one row tile
-  const bool tm2 = !wide && M % 64 == 0 && (long)nbatch * (M / 32) * 4 >= 64;
+  static const char* const dbg = getenv("DRQ_TRUNK_DBG");       // development knobs (read once)
+  const bool force_tm2 = dbg && (atoi(dbg) & 4);
+  const bool tm2 = !wide && M % 64 == 0 && ((long)nbatch * (M / 32) * 4 >= 64 || force_tm2);
   const int rows = tm2 ? M / 64 : M / 32;
   int blocks_k = (cus + nbatch * rows - 1) / (nbatch * rows);
   if (blocks_k * 4 > steps) blocks_k = steps / 4;
-  static const char* const dbg = getenv("DRQ_TRUNK_DBG");       // development knobs (read once)
   if (dbg) {
     const int d = atoi(dbg);
     if (d & 1) g.a_bytes = g.b_bytes = 0;               // every load out of range: MFMA time only
