@@ -661,7 +661,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad2_kernel(WgradArgs a) {
 // LDS and fetches only ONE new input row + ONE dY row per output row (22 instead of 44 load / LDS-write
 // instructions).  Those are spread over the k-steps of the current row's MFMA loop (loads early, LDS writes
 // 7 steps later, into the ring slot / dY buffer the loop does not read), so staging hides under the MFMAs
-// although the wave is alone on its SIMD.  Disabled loads are sent out of range of the buffer descriptor
+// although the wave is alone on its SIMD.  A disabled load gets a zero-length buffer descriptor (returns 0)
 // instead of being branched around (branches would force vmcnt(0) waits).
 unsigned long long* g_wgrad_stamps = nullptr;   // set by drq_dev_wgrad_stamps (undeclared development hook)
 
