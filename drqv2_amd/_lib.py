@@ -45,6 +45,7 @@ PROTOTYPES = {
     "drq_conv3x3_wgrad_ws_bytes": (SZ, []),
     "drq_gemm_f32": (I, [P, L, I, P, L, I, P, L, I, I, I, I, L, L, L, P, L, I, P, I, L, I, I, I, P, SZ, P]),
     "drq_gemm_batched_f32": (I, [I, P, L, I, P, L, I, P, L, I, I, I, P, I, P, I, P, I, I, I, P, SZ, P]),
+    "drq_gemm_batched_partial": (I, [I, P, L, I, P, L, I, P, L, I, I, I, P, P, SZ, C.POINTER(I), P]),
     "drq_qout_fwd": (I, [I, P, P, P, P, I, I, P]),
     "drq_qout_bwd": (I, [I, P, P, P, P, P, P, I, I, P]),
     "drq_ln_tanh_fwd_multi": (I, [I, P, I, P, P, P, P, P, P, I, I, P]),
@@ -81,15 +82,20 @@ class DrqError(RuntimeError):
     pass
 
 
-def load():
-    """Returns the loaded library; raises if it has not been built (python -m drqv2_amd.build)."""
+def load(dev=False):
+    """Returns the loaded library; raises if it has not been built (python -m drqv2_amd.build).
+    dev=True (tools/ only, must be the first load of the process): the -DDRQ_DEV build with the timing ablations
+    and time-stamp hooks (python -m drqv2_amd.build --dev); the product path never asks for it."""
     global _lib
     if _lib is not None:
+        if dev and not hasattr(_lib, "drq_dev_conv_variant"):
+            raise DrqError("the product library is already loaded in this process; load(dev=True) must come first")
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise DrqError(f"{LIB_PATH} is missing: build it with `python -m drqv2_amd.build` "
+    path = os.path.join(HERE, "libdrqv2_hip_dev.so") if dev else LIB_PATH
+    if not os.path.exists(path):
+        raise DrqError(f"{path} is missing: build it with `python -m drqv2_amd.build{' --dev' if dev else ''}` "
                        "(hipcc --offload-arch=gfx950).  The DrQ-v2 update path has no fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)       # AttributeError = ABI mismatch, also loud
         fn.restype = res

@@ -1,4 +1,7 @@
-"""Build libdrqv2_hip.so (gfx950 only) in-tree with hipcc.  `python -m drqv2_amd.build [--force]`."""
+"""Build libdrqv2_hip.so (gfx950 only) in-tree with hipcc.  `python -m drqv2_amd.build [--force] [--dev]`.
+
+--dev builds libdrqv2_hip_dev.so with -DDRQ_DEV: the same kernels plus the timing ablations, time-stamp hooks and
+environment knobs that tools/ uses.  The product library has none of them (no getenv, no drq_dev_* exports)."""
 import os
 import subprocess
 import sys
@@ -6,8 +9,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdrqv2_hip.so")
-SOURCES = ["conv.hip", "gemm.hip", "gemm2.hip", "skinny.hip", "elementwise.hip", "step.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+LIB_DEV = os.path.join(HERE, "libdrqv2_hip_dev.so")
+SOURCES = ["conv.hip", "conv1aug.hip", "gemm.hip", "gemm2.hip", "skinny.hip", "elementwise.hip", "step.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
+         "-fvisibility=hidden"]
 
 
 def _hipcc():
@@ -17,23 +22,29 @@ def _hipcc():
     return "hipcc"
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def _sources():
+    return [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def needs_build(lib=LIB):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "drqv2_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force=False, verbose=True):
-    if not force and not needs_build():
-        return LIB
-    objdir = os.path.join(HERE, "build")
+def build(force=False, verbose=True, dev=False):
+    lib = LIB_DEV if dev else LIB
+    if not force and not needs_build(lib):
+        return lib
+    objdir = os.path.join(HERE, "build", "dev" if dev else "prod")
     os.makedirs(objdir, exist_ok=True)
+    flags = FLAGS + (["-DDRQ_DEV"] if dev else [])
     procs = []
-    for src in SOURCES:
+    for src in _sources():
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [_hipcc()] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [_hipcc()] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((obj, subprocess.Popen(cmd)))
@@ -42,13 +53,12 @@ def build(force=False, verbose=True):
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed for {obj}")
         objs.append(obj)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    print(build(force="--force" in sys.argv, dev="--dev" in sys.argv))

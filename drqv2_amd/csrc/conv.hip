@@ -41,7 +41,10 @@ struct ConvArgs {
   unsigned long long* stamps;   // development only (ABL & 4): per-wave s_memtime stamps, 32 per wave
 };
 
-unsigned long long* g_conv_stamps = nullptr;   // set by drq_dev_conv_stamps (undeclared development hook)
+#ifdef DRQ_DEV   // development build only (tools/): per-wave time stamps, see drq_dev_* at the end of the file
+unsigned long long* g_conv_stamps = nullptr;
+int g_conv_variant = -1;          // drq_dev_conv_variant overrides DRQ_CONV_VARIANT
+#endif
 
 // BLK = workgroups per CU the kernel is tuned for (8 waves each): 2 -> 4 waves/SIMD (<=128 VGPR)
 // ABL (development only): 1 = skip the input loads, 2 = skip the LDS weight reads, 3 = both (timing ablations)
@@ -329,7 +332,11 @@ struct WgradGeom {
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-unsigned long long* g_wgrad1_stamps = nullptr;   // set by drq_dev_wgrad1_stamps (undeclared development hook)
+#ifdef DRQ_DEV
+unsigned long long* g_wgrad1_stamps = nullptr;
+#else
+constexpr unsigned long long* g_wgrad1_stamps = nullptr;
+#endif
 
 template <int CIN, int HIN, int STRIDE, bool STAMP = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(WgradArgs a, unsigned long long* stamps = nullptr) {
@@ -663,7 +670,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad2_kernel(WgradArgs a) {
 // 7 steps later, into the ring slot / dY buffer the loop does not read), so staging hides under the MFMAs
 // although the wave is alone on its SIMD.  A disabled load gets a zero-length buffer descriptor (returns 0)
 // instead of being branched around (branches would force vmcnt(0) waits).
-unsigned long long* g_wgrad_stamps = nullptr;   // set by drq_dev_wgrad_stamps (undeclared development hook)
+#ifdef DRQ_DEV
+unsigned long long* g_wgrad_stamps = nullptr;
+#else
+constexpr unsigned long long* g_wgrad_stamps = nullptr;
+#endif
 
 // The k-step loop is written for a wave that is alone on its SIMD.  Measured there (tools/mfma_issue_probe.hip):
 // every VALU instruction between the MFMAs costs ~5 cycles of matrix-pipe time (LDS and scalar instructions cost
@@ -1025,23 +1036,20 @@ int launch_conv_v(const ConvArgs& a, hipStream_t st) {
   return DRQ_OK;
 }
 
-// DRQ_CONV_VARIANT (development knob, read once): timing ablations of the forward kernel
-int g_conv_variant = -1;          // drq_dev_conv_variant (undeclared development hook) overrides the env var
-inline int conv_variant() {
-  if (g_conv_variant < 0) {
-    const char* e = getenv("DRQ_CONV_VARIANT");
-    g_conv_variant = e ? atoi(e) : 0;
-  }
-  return g_conv_variant;
-}
-
 template <int CIN, int HIN, int STRIDE>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
   if (a.mask) {
     if constexpr (CIN == 32) return launch_conv_v<CIN, HIN, STRIDE, 2, 1, 0, true>(a, st);
     else return DRQ_EARG;
   }
-  switch (conv_variant()) {
+#ifdef DRQ_DEV
+  // DRQ_CONV_VARIANT / drq_dev_conv_variant: timing ablations of the forward kernel.  Development build only
+  // (tools/conv_ab.py, tools/conv_stamps.py): variants 6-8 skip loads and compute garbage on purpose.
+  if (g_conv_variant < 0) {
+    const char* e = getenv("DRQ_CONV_VARIANT");
+    g_conv_variant = e ? atoi(e) : 0;
+  }
+  switch (g_conv_variant) {
     case 1: return launch_conv_v<CIN, HIN, STRIDE, 2, 2>(a, st);        // 2 tiles per wave share each weight read
     case 2: return launch_conv_v<CIN, HIN, STRIDE, 1, 2>(a, st);
     case 4: return launch_conv_v<CIN, HIN, STRIDE, 1, 4>(a, st);        // 1 workgroup/CU, 4 accumulator chains/wave
@@ -1051,21 +1059,29 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     case 10: case 11: case 12: {                                        // + per-wave time stamps
       ConvArgs b = a;
       b.stamps = g_conv_stamps;
-      if (conv_variant() == 10) return launch_conv_v<CIN, HIN, STRIDE, 2, 1, 4>(b, st);        // start/end only
-      if (conv_variant() == 11) return launch_conv_v<CIN, HIN, STRIDE, 2, 1, 12>(b, st);       // + every tile
+      if (g_conv_variant == 10) return launch_conv_v<CIN, HIN, STRIDE, 2, 1, 4>(b, st);        // start/end only
+      if (g_conv_variant == 11) return launch_conv_v<CIN, HIN, STRIDE, 2, 1, 12>(b, st);       // + every tile
       return launch_conv_v<CIN, HIN, STRIDE, 2, 1, 7>(b, st);                                  // MFMA only, start/end
     }
-    default: return launch_conv_v<CIN, HIN, STRIDE, 2, 1>(a, st);
+    default: break;
   }
+#endif
+  return launch_conv_v<CIN, HIN, STRIDE, 2, 1>(a, st);
 }
 
-inline int wgrad_variant() {     // DRQ_WGRAD_VARIANT (development knob, read once): 2 = block-shared input rows
+// 1 = rolling-tile kernel (conv2..4), the product path.  The development build can select 2 (block-shared input
+// rows, measured slower) through DRQ_WGRAD_VARIANT.
+inline int wgrad_variant() {
+#ifdef DRQ_DEV
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("DRQ_WGRAD_VARIANT");
     v = e ? atoi(e) : 1;
   }
   return v;
+#else
+  return 1;
+#endif
 }
 
 // defer: run only the partial-sum kernel (records in ws, their count in *nblocks_out); the caller reduces several
@@ -1093,7 +1109,8 @@ int launch_wgrad(const WgradArgs& a0, float* dw, float* db, float* ws, size_t ws
   if (((size_t)ws & 15) != 0) return DRQ_EARG;          // partial records are written 16 bytes at a time
   WgradArgs a = a0;
   a.part = ws;
-  static bool attr_set = false;
+  static bool attr_set_dev[kMaxDevices] = {};
+  bool& attr_set = attr_set_dev[drq_device()];
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel<CIN, HIN, STRIDE>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds1 * 4);
@@ -1108,7 +1125,8 @@ int launch_wgrad(const WgradArgs& a0, float* dw, float* db, float* ws, size_t ws
       constexpr int wave3 = 4 * CIN * G::XP + 2 * 32 * G::DP + 128;
       constexpr int lds3 = (4 * wave3 > 4 * G::PART) ? 4 * wave3 : 4 * G::PART;
       static_assert(lds3 * 4 <= 160 * 1024, "rolling tile too large");
-      static bool attr3 = false;
+      static bool attr3_dev[kMaxDevices] = {};
+      bool& attr3 = attr3_dev[drq_device()];
       if (!attr3) {
         hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wgrad3_kernel<HIN>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds3 * 4);
@@ -1116,10 +1134,12 @@ int launch_wgrad(const WgradArgs& a0, float* dw, float* db, float* ws, size_t ws
         attr3 = true;
       }
       if (HIN == 41 && g_wgrad_stamps) {
-        hipFuncSetAttribute((const void*)conv3x3_wgrad3_kernel<41, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            lds3 * 4);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad3_kernel<41, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds3 * 4);
         WgradArgs as = a;
+#ifdef DRQ_DEV
         if (getenv("DRQ_WGRAD_NOLOAD")) as.x_bytes = as.dy_bytes = 0;     // every load out of range: no memory traffic
+#endif
         hipLaunchKernelGGL((conv3x3_wgrad3_kernel<41, true>), dim3((unsigned)blocks), dim3(256), lds3 * 4, st, as,
                            g_wgrad_stamps);
       } else
@@ -1197,14 +1217,18 @@ int drq_conv3x3_wgrad_reduce_multi(int n, const float* const* part, const int* n
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-// development hook (not part of the ABI): device buffer of 32 u64 per wave for DRQ_CONV_VARIANT=10
+#ifdef DRQ_DEV
+// development hooks (libdrqv2_hip_dev.so only, never in the product library): device buffer of 32 u64 per wave
+#pragma GCC visibility push(default)
 void drq_dev_conv_stamps(void* p) { g_conv_stamps = (unsigned long long*)p; }
 void drq_dev_wgrad_stamps(void* p) { g_wgrad_stamps = (unsigned long long*)p; }
 void drq_dev_wgrad1_stamps(void* p) { g_wgrad1_stamps = (unsigned long long*)p; }
 void drq_dev_conv_variant(int v) { g_conv_variant = v; }
+#pragma GCC visibility pop
+#endif
 
 // y = relu?(conv3x3(x, w) + bias); x [nb][cin][hin][hin], y written with the given strides.
-int drq_conv3x3_fwd(const float* x, const float* w, const float* bias, float* y, int nb, int cin, int hin,
+DRQ_API int drq_conv3x3_fwd(const float* x, const float* w, const float* bias, float* y, int nb, int cin, int hin,
                     int stride, int relu, long y_bs, long y_cs, long y_rs, long y_off, hipStream_t st) {
   if (!x || !w || !y || nb <= 0) return DRQ_EARG;
   const size_t xb = (size_t)nb * cin * hin * hin * 4;
@@ -1223,7 +1247,7 @@ int drq_conv3x3_fwd(const float* x, const float* w, const float* bias, float* y,
 
 // dx = conv_transpose(dy, w) * (mask > 0): dy_pad is the pre-activation gradient stored zero-padded by 2
 // ([nb][32][hout+4][hout+4]); the result has the layer-input size hin = hout+2 and is written with strides.
-int drq_conv3x3_dgrad(const float* dy_pad, const float* w, const float* mask, float* dx, int nb, int hout,
+DRQ_API int drq_conv3x3_dgrad(const float* dy_pad, const float* w, const float* mask, float* dx, int nb, int hout,
                       long dx_bs, long dx_cs, long dx_rs, long dx_off, hipStream_t st) {
   if (!dy_pad || !w || !dx || nb <= 0) return DRQ_EARG;
   const int hp = hout + 4;
@@ -1241,7 +1265,7 @@ int drq_conv3x3_dgrad(const float* dy_pad, const float* w, const float* mask, fl
 }
 
 // dw[32][cin][3][3], db[32] from the layer input x and the pre-activation gradient dy (strided view).
-int drq_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, int nb, int cin, int hin,
+DRQ_API int drq_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, int nb, int cin, int hin,
                       int stride, long dy_bs, long dy_cs, long dy_rs, long dy_off, float* ws, size_t ws_bytes,
                       hipStream_t st) {
   if (!x || !dy || !dw || !db || !ws || nb <= 0) return DRQ_EARG;
@@ -1258,6 +1282,6 @@ int drq_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, int
   return DRQ_EARG;
 }
 
-size_t drq_conv3x3_wgrad_ws_bytes(void) { return (size_t)1024 * (9 * 1024 + 64) * sizeof(float); }
+DRQ_API size_t drq_conv3x3_wgrad_ws_bytes(void) { return (size_t)1024 * (9 * 1024 + 64) * sizeof(float); }
 
 }  // extern "C"

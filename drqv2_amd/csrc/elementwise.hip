@@ -202,8 +202,7 @@ __global__ __launch_bounds__(256) void aug_rows_kernel(const uint8_t* __restrict
 // rows-in-LDS launch when the frame layout allows it (dword rows); returns false when it does not
 bool launch_aug_rows(const uint8_t* obs, const float* shift, const uint8_t* obs1, const float* shift1,
                      const float* base, float* out, int n, int c, int h, int pad, int fuse_norm, hipStream_t st) {
-  static const bool off = getenv("DRQ_AUG_VARIANT") && atoi(getenv("DRQ_AUG_VARIANT")) == 0;   // development knob
-  if (off || h % 4 != 0 || h > 256 || n > 65535 || ((uintptr_t)obs & 3) || (obs1 && ((uintptr_t)obs1 & 3))) return false;
+  if (h % 4 != 0 || h > 256 || n > 65535 || ((uintptr_t)obs & 3) || (obs1 && ((uintptr_t)obs1 & 3))) return false;
   const int R = 256 / h, NR = R + 2;
   const size_t lds = (size_t)c * NR * h;
   if (R < 1 || lds > 64 * 1024) return false;
@@ -1048,7 +1047,7 @@ int drq_ln_tanh_bwd_part(const float* dh0, int ld0, const float* dh1, int ld1, c
                          float* dgamma, float* dbeta, int rows, int F, const float* part, int splitk, int nprob,
                          int ldp, hipStream_t st);
 
-int drq_aug_fwd(const uint8_t* obs, const float* shift_xy, const float* base_grid, float* out, int n, int c,
+DRQ_API int drq_aug_fwd(const uint8_t* obs, const float* shift_xy, const float* base_grid, float* out, int n, int c,
                 int hw, int pad, int fuse_norm, hipStream_t st) {
   if (!obs || !shift_xy || !base_grid || !out || n <= 0 || c <= 0 || hw <= 0 || pad < 0) return DRQ_EARG;
   if (launch_aug_rows(obs, shift_xy, nullptr, nullptr, base_grid, out, n, c, hw, pad, fuse_norm, st)) {
@@ -1079,7 +1078,7 @@ int drq_aug_fwd_pair(const uint8_t* obs, const float* shift, const uint8_t* obs1
 }
 
 // same op on a float frame (RandomShiftsAug.forward is handed obs.float(), drqv2.py:241)
-int drq_aug_fwd_f32(const float* x, const float* shift_xy, const float* base_grid, float* out, int n, int c, int hw,
+DRQ_API int drq_aug_fwd_f32(const float* x, const float* shift_xy, const float* base_grid, float* out, int n, int c, int hw,
                     int pad, hipStream_t st) {
   if (!x || !shift_xy || !base_grid || !out || n <= 0 || c <= 0 || hw <= 0 || pad < 0) return DRQ_EARG;
   const long total = (long)n * hw * hw;
@@ -1089,7 +1088,7 @@ int drq_aug_fwd_f32(const float* x, const float* shift_xy, const float* base_gri
   return DRQ_OK;
 }
 
-int drq_ln_tanh_fwd(const float* z, int ldz, const float* gamma, const float* beta, float* out, int ldo,
+DRQ_API int drq_ln_tanh_fwd(const float* z, int ldz, const float* gamma, const float* beta, float* out, int ldo,
                     float* xhat, float* rstd, int rows, int F, hipStream_t st) {
   if (!z || !gamma || !beta || !out || rows <= 0 || F <= 0 || F > 256) return DRQ_EARG;
   LnArgs a{};
@@ -1101,7 +1100,7 @@ int drq_ln_tanh_fwd(const float* z, int ldz, const float* gamma, const float* be
 }
 
 // two LayerNorm+tanh problems of the same (rows, F) in one launch (actor trunk + critic trunk)
-int drq_ln_tanh_fwd2(const float* z0, const float* z1, int ldz, const float* gamma0, const float* beta0,
+DRQ_API int drq_ln_tanh_fwd2(const float* z0, const float* z1, int ldz, const float* gamma0, const float* beta0,
                      const float* gamma1, const float* beta1, float* out0, int ldo0, float* out1, int ldo1,
                      float* xhat0, float* rstd0, float* xhat1, float* rstd1, int rows, int F, hipStream_t st) {
   if (!z0 || !z1 || !out0 || !out1 || rows <= 0 || F <= 0 || F > 256) return DRQ_EARG;
@@ -1114,7 +1113,7 @@ int drq_ln_tanh_fwd2(const float* z0, const float* z1, int ldz, const float* gam
   return DRQ_OK;
 }
 
-int drq_ln_tanh_bwd(const float* dh0, int ld0, const float* dh1, int ld1, const float* h, int ldh,
+DRQ_API int drq_ln_tanh_bwd(const float* dh0, int ld0, const float* dh1, int ld1, const float* h, int ldh,
                     const float* xhat, const float* rstd, const float* gamma, float* dz, float* dln,
                     float* dgamma, float* dbeta, int rows, int F, hipStream_t st) {
   return drq_ln_tanh_bwd_part(dh0, ld0, dh1, ld1, h, ldh, xhat, rstd, gamma, dz, dln, dgamma, dbeta, rows, F, nullptr, 0,
@@ -1139,7 +1138,7 @@ int drq_ln_tanh_bwd_part(const float* dh0, int ld0, const float* dh1, int ld1, c
 }
 
 // nz (<= 8) Q-head output layers in one launch; host arrays of device pointers
-int drq_qout_fwd(int nz, const float* const* h, const float* const* w, const float* const* b, float* const* q, int B,
+DRQ_API int drq_qout_fwd(int nz, const float* const* h, const float* const* w, const float* const* b, float* const* q, int B,
                  int H, hipStream_t st) {
   if (nz <= 0 || nz > 8 || !h || !w || !b || !q || B <= 0 || H <= 0) return DRQ_EARG;
   QOutArgs a{};
@@ -1154,7 +1153,7 @@ int drq_qout_fwd(int nz, const float* const* h, const float* const* w, const flo
 }
 
 // dh = (dq w^T) * (h > 0);  dw = dq^T h, db = sum dq when the dw/db arrays are given
-int drq_qout_bwd(int nz, const float* const* dq, const float* const* h, const float* const* w, float* const* dh,
+DRQ_API int drq_qout_bwd(int nz, const float* const* dq, const float* const* h, const float* const* w, float* const* dh,
                  float* const* dw, float* const* db, int B, int H, hipStream_t st) {
   if (nz <= 0 || nz > 8 || !dq || !h || !w || !dh || B <= 0 || H <= 0) return DRQ_EARG;
   QOutBwdArgs a{};
@@ -1198,7 +1197,7 @@ int drq_qout_bwd_td(const float* tq1, const float* tq2, const float* q1, const f
 }
 
 // n (<= 4) LayerNorm+tanh problems of the same (rows, F) in one launch
-int drq_ln_tanh_fwd_multi(int n, const float* const* z, int ldz, const float* const* gamma, const float* const* beta,
+DRQ_API int drq_ln_tanh_fwd_multi(int n, const float* const* z, int ldz, const float* const* gamma, const float* const* beta,
                           float* const* out, const int* ldo, float* const* xhat, float* const* rstd, int rows, int F,
                           hipStream_t st) {
   return drq_ln_tanh_fwd_multi_ex(n, z, ldz, gamma, beta, out, ldo, xhat, rstd, rows, F, nullptr, nullptr, 0, st);
@@ -1244,7 +1243,7 @@ int drq_ln_tanh_fwd_multi_part(int n, const float* const* z, int ldz, const floa
   return DRQ_OK;
 }
 
-int drq_colsum(const float* dy, long ld, long dy_bs, float* out, long out_bs, int M, int N, int nbatch,
+DRQ_API int drq_colsum(const float* dy, long ld, long dy_bs, float* out, long out_bs, int M, int N, int nbatch,
                hipStream_t st) {
   if (!dy || !out || M <= 0 || N <= 0 || nbatch <= 0) return DRQ_EARG;
   hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, nbatch), dim3(1024), 0, st, dy, ld, dy_bs, out, out_bs, M, N);
@@ -1252,7 +1251,7 @@ int drq_colsum(const float* dy, long ld, long dy_bs, float* out, long out_bs, in
   return DRQ_OK;
 }
 
-int drq_trunc_normal_sample(const float* pre_tanh, const float* noise, float std, float clip, int use_clip,
+DRQ_API int drq_trunc_normal_sample(const float* pre_tanh, const float* noise, float std, float clip, int use_clip,
                             float* mu_out, float* a_out, long lda_out, int B, int A, hipStream_t st) {
   if (!pre_tanh || !noise || !a_out || B <= 0 || A <= 0) return DRQ_EARG;
   hipLaunchKernelGGL(sample_action_kernel, dim3((B * A + 255) / 256), dim3(256), 0, st, pre_tanh, noise, std, clip,
@@ -1293,14 +1292,14 @@ int drq_policy_out_bwd(const float* da1, const float* da2, long ld, int col0, co
   return DRQ_OK;
 }
 
-int drq_copy_cols(const float* src, int ld_src, float* dst, long ld_dst, int B, int A, hipStream_t st) {
+DRQ_API int drq_copy_cols(const float* src, int ld_src, float* dst, long ld_dst, int B, int A, hipStream_t st) {
   if (!src || !dst || B <= 0 || A <= 0) return DRQ_EARG;
   hipLaunchKernelGGL(copy_cols_kernel, dim3((B * A + 255) / 256), dim3(256), 0, st, src, ld_src, dst, ld_dst, B, A);
   DRQ_LAUNCH_CHECK();
   return DRQ_OK;
 }
 
-int drq_td_mse(const float* tq1, const float* tq2, const float* q1, const float* q2, const float* reward,
+DRQ_API int drq_td_mse(const float* tq1, const float* tq2, const float* q1, const float* q2, const float* reward,
                const float* discount, float* dq1, float* dq2, float* sums, int B, float inv_global_B,
                hipStream_t st) {
   if (!tq1 || !tq2 || !q1 || !q2 || !reward || !discount || !dq1 || !dq2 || !sums || B <= 0) return DRQ_EARG;
@@ -1321,12 +1320,12 @@ int drq_actor_loss_ex(const float* q1, const float* q2, const float* a, long lda
   return DRQ_OK;
 }
 
-int drq_actor_loss(const float* q1, const float* q2, const float* a, long lda, const float* mu, float std,
+DRQ_API int drq_actor_loss(const float* q1, const float* q2, const float* a, long lda, const float* mu, float std,
                    float* dq1, float* dq2, float* sums, int B, int A, float inv_global_B, hipStream_t st) {
   return drq_actor_loss_ex(q1, q2, a, lda, mu, std, dq1, dq2, sums, B, A, inv_global_B, nullptr, 0u, st);
 }
 
-int drq_actor_dmu(const float* dha1, const float* dha2, long ld, int col0, const float* mu, float* dpre, int B,
+DRQ_API int drq_actor_dmu(const float* dha1, const float* dha2, long ld, int col0, const float* mu, float* dpre, int B,
                   int A, hipStream_t st) {
   if (!dha1 || !dha2 || !mu || !dpre || B <= 0 || A <= 0) return DRQ_EARG;
   hipLaunchKernelGGL(actor_dmu_kernel, dim3((B * A + 255) / 256), dim3(256), 0, st, dha1, dha2, ld, col0, mu, dpre,
@@ -1360,7 +1359,7 @@ int drq_adam_flat2(float* p0, const float* g0, float* m0, float* v0, long n0, lo
   return DRQ_OK;
 }
 
-int drq_adam_flat(float* p, const float* g, float* m, float* v, long n, double lr, long step, float gscale,
+DRQ_API int drq_adam_flat(float* p, const float* g, float* m, float* v, long n, double lr, long step, float gscale,
                   float* tgt, double tau, hipStream_t st) {
   if (!p || !g || !m || !v || n <= 0 || step <= 0) return DRQ_EARG;
   const double bc1 = 1.0 - pow(0.9, (double)step);
@@ -1373,7 +1372,7 @@ int drq_adam_flat(float* p, const float* g, float* m, float* v, long n, double l
   return DRQ_OK;
 }
 
-int drq_ema_flat(const float* p, float* t, long n, double tau, hipStream_t st) {
+DRQ_API int drq_ema_flat(const float* p, float* t, long n, double tau, hipStream_t st) {
   if (!p || !t || n <= 0) return DRQ_EARG;
   hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, t, n, (float)tau, (float)(1.0 - tau));
   DRQ_LAUNCH_CHECK();
@@ -1381,7 +1380,7 @@ int drq_ema_flat(const float* p, float* t, long n, double tau, hipStream_t st) {
 }
 
 // Device-side replay batch assembly (replay_buffer.py:142-160), see nstep_gather_kernel.
-int drq_nstep_gather(const uint8_t* frames, const float* action, const float* reward, const float* discount,
+DRQ_API int drq_nstep_gather(const uint8_t* frames, const float* action, const float* reward, const float* discount,
                      const long* pos, int B, int A, long frame_bytes, int nstep, float gamma, uint8_t* obs,
                      float* act_out, float* rew_out, float* disc_out, uint8_t* next_obs, hipStream_t st) {
   if (!frames || !action || !reward || !discount || !pos || !obs || !act_out || !rew_out || !disc_out || !next_obs)
@@ -1396,21 +1395,21 @@ int drq_nstep_gather(const uint8_t* frames, const float* action, const float* re
 }
 
 // Encoder input conversion without augmentation (drqv2.py:64 on a uint8 frame, as act() does)
-int drq_u8_normalize(const uint8_t* x, float* y, long n, hipStream_t st) {
+DRQ_API int drq_u8_normalize(const uint8_t* x, float* y, long n, hipStream_t st) {
   if (!x || !y || n <= 0) return DRQ_EARG;
   hipLaunchKernelGGL(u8_normalize_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, y, n);
   DRQ_LAUNCH_CHECK();
   return DRQ_OK;
 }
 
-int drq_tanh(const float* x, float* y, long n, hipStream_t st) {
+DRQ_API int drq_tanh(const float* x, float* y, long n, hipStream_t st) {
   if (!x || !y || n <= 0) return DRQ_EARG;
   hipLaunchKernelGGL(tanh_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, y, n);
   DRQ_LAUNCH_CHECK();
   return DRQ_OK;
 }
 
-int drq_fill(float* p, long n, float v, hipStream_t st) {
+DRQ_API int drq_fill(float* p, long n, float v, hipStream_t st) {
   if (!p || n <= 0) return DRQ_EARG;
   hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, n, v);
   DRQ_LAUNCH_CHECK();

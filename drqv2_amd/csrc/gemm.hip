@@ -358,8 +358,8 @@ __global__ void splitk_reduce_kernel(GemmArgs g) {
 }
 
 // set by drq_gemm_batched_partial around one call: keep the split-K partials, the caller reduces them itself
-bool g_leave_partials = false;
-int g_last_splitk = 1;
+thread_local bool g_leave_partials = false;   // call-scoped flag of drq_gemm_batched_partial (per host thread)
+thread_local int g_last_splitk = 1;
 
 template <int TM, int TN, bool A_KC, bool B_KC, bool V4, int BK = BK0>
 int launch(const GemmArgs& g, hipStream_t st) {
@@ -412,7 +412,7 @@ int drq_gemm2(int nbatch, const float* const* A, long lda, int a_kc, const float
 extern "C" {
 
 // See include/drqv2_hip.h.  Host arrays of nbatch (<= 8) device pointers; bias/aux/rowsum arrays may be null.
-int drq_gemm_batched_f32(int nbatch, const float* const* A, long lda, int a_kc, const float* const* B, long ldb,
+DRQ_API int drq_gemm_batched_f32(int nbatch, const float* const* A, long lda, int a_kc, const float* const* B, long ldb,
                          int b_kc, float* const* C, long ldc, int M, int N, int K, const float* const* bias, int relu,
                          const float* const* aux, int ldaux, float* const* rowsum, int scatter_hw, int tile,
                          int splitk, float* ws, size_t ws_bytes, hipStream_t st) {
@@ -482,11 +482,15 @@ int drq_gemm_batched_f32(int nbatch, const float* const* A, long lda, int a_kc, 
 
 // internal (step.hip): same call, but a split-K result stays in `ws` as partials [nbatch*splitk][M][N] (no bias, no
 // epilogue) and *splitk_out says how many there are per problem; 1 = the result went to C as usual
-int drq_gemm_batched_partial(int nbatch, const float* const* A, long lda, int a_kc, const float* const* B, long ldb,
+DRQ_API int drq_gemm_batched_partial(int nbatch, const float* const* A, long lda, int a_kc, const float* const* B, long ldb,
                              int b_kc, float* const* C, long ldc, int M, int N, int K, const float* const* bias,
                              float* ws, size_t ws_bytes, int* splitk_out, hipStream_t st) {
   // the trunk forward (k-contiguous operands, N <= 64, long K) has its own kernel
-  static const bool no_trunk = getenv("DRQ_NO_TRUNK_KERNEL") != nullptr;     // development knob (A/B against the tiled GEMM)
+#ifdef DRQ_DEV
+  static const bool no_trunk = getenv("DRQ_NO_TRUNK_KERNEL") != nullptr;     // development build: A/B against the tiled GEMM
+#else
+  constexpr bool no_trunk = false;
+#endif
   if (a_kc && b_kc && N <= 128 && K >= 4096 && ldc == N && !no_trunk) {
     int sk = 1;
     const int rc = drq_trunk_fwd_partial(nbatch, A, lda, B, ldb, M, N, K, ws, ws_bytes, &sk, st);
@@ -506,7 +510,7 @@ int drq_gemm_batched_partial(int nbatch, const float* const* A, long lda, int a_
 }
 
 // strided-batch form of the same call
-int drq_gemm_f32(const float* A, long lda, int a_kc, const float* B, long ldb, int b_kc, float* C, long ldc,
+DRQ_API int drq_gemm_f32(const float* A, long lda, int a_kc, const float* B, long ldb, int b_kc, float* C, long ldc,
                  int M, int N, int K, int nbatch, long a_bs, long b_bs, long c_bs, const float* bias, long bias_bs,
                  int relu, const float* aux, int ldaux, long aux_bs, int scatter_hw, int tile, int splitk,
                  float* ws, size_t ws_bytes, hipStream_t st) {

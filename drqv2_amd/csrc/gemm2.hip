@@ -420,7 +420,11 @@ int drq_trunk_fwd_partial(int nbatch, const float* const* A, long lda, const flo
   // extra waves hide
   const int steps = K / 32, cus = drq_num_cus();
   const bool wide = N > 64;               // four column tiles per wave, one row tile
-  static const char* const dbg = getenv("DRQ_TRUNK_DBG");       // development knobs (read once)
+#ifdef DRQ_DEV
+  static const char* const dbg = getenv("DRQ_TRUNK_DBG");       // development build only (tools/trunk_bench.py)
+#else
+  constexpr const char* dbg = nullptr;
+#endif
   const bool force_tm2 = dbg && (atoi(dbg) & 4);
   const bool tm2 = !wide && M % 64 == 0 && ((long)nbatch * (M / 32) * 4 >= 64 || force_tm2);
   const int rows = tm2 ? M / 64 : M / 32;

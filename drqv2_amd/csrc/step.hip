@@ -4,11 +4,7 @@
 #include "common.h"
 #include "../../include/drqv2_hip.h"
 
-// gemm.hip / elementwise.hip (internal): trunk GEMM that leaves its split-K partials, LayerNorm that sums them
-extern "C" int drq_gemm_batched_partial(int nbatch, const float* const* A, long lda, int a_kc, const float* const* B,
-                                        long ldb, int b_kc, float* const* C, long ldc, int M, int N, int K,
-                                        const float* const* bias, float* ws, size_t ws_bytes, int* splitk_out,
-                                        hipStream_t st);
+// elementwise.hip (internal): LayerNorm that sums the split-K partials of drq_gemm_batched_partial
 extern "C" int drq_ln_tanh_fwd_multi_part(int n, const float* const* z, int ldz, const float* const* gamma,
                                           const float* const* beta, float* const* out, const int* ldo,
                                           float* const* xhat, float* const* rstd, int rows, int F,
@@ -620,9 +616,9 @@ int check_step(const DrqStep* s) {
 
 extern "C" {
 
-int drq_abi_version(void) { return 3; }
+DRQ_API int drq_abi_version(void) { return 3; }
 
-int drq_param_layout(int C, int A, int F, int H, long* out, int cap) {
+DRQ_API int drq_param_layout(int C, int A, int F, int H, long* out, int cap) {
   if (!out || cap < DRQ_PARAM_LAYOUT_LEN || C <= 0 || A <= 0 || F <= 0 || H <= 0) return DRQ_EARG;
   const ParamLayout L = param_layout(C, A, F, H);
   int n = 0;
@@ -632,17 +628,17 @@ int drq_param_layout(int C, int A, int F, int H, long* out, int cap) {
   return n;
 }
 
-size_t drq_step_ws_bytes(int B, int C, int A, int F, int H) {
+DRQ_API size_t drq_step_ws_bytes(int B, int C, int A, int F, int H) {
   if (B <= 0 || C <= 0 || A <= 0 || F <= 0 || H <= 0) return 0;
   return (size_t)ws_layout(B, C, A, F, H).total * sizeof(float);
 }
 
-long drq_step_ws_offset(int B, int C, int A, int F, int H, int id) {
+DRQ_API long drq_step_ws_offset(int B, int C, int A, int F, int H, int id) {
   if (id < 0 || id >= DRQ_WS_NBUF_PUBLIC) return -1;
   return ws_layout(B, C, A, F, H).off[id];
 }
 
-int drq_update_phase(const DrqStep* s, int phase) {
+DRQ_API int drq_update_phase(const DrqStep* s, int phase) {
   CK(check_step(s));
   if (!s->obs || !s->next_obs || !s->action || !s->reward || !s->discount || !s->shift_obs || !s->shift_next ||
       !s->noise_critic || !s->noise_actor || !s->base_grid || !s->grads || !s->adam_m || !s->adam_v || !s->sums)
@@ -665,11 +661,11 @@ int drq_update_phase(const DrqStep* s, int phase) {
   return 0;
 }
 
-int drq_publish_sums(const float* sums, float* sums_host, unsigned seq, drq_stream_t stream) {
+DRQ_API int drq_publish_sums(const float* sums, float* sums_host, unsigned seq, drq_stream_t stream) {
   return publish_sums(sums, sums_host, seq, (hipStream_t)stream);
 }
 
-int drq_act_forward(const DrqStep* s, const uint8_t* obs, int n, float* mu_out) {
+DRQ_API int drq_act_forward(const DrqStep* s, const uint8_t* obs, int n, float* mu_out) {
   CK(check_step(s));
   if (!obs || !mu_out || n <= 0 || n > 2 * s->B) return DRQ_EARG;
   Ctx c{s, param_layout(s->C, s->A, s->F, s->H), ws_layout(s->B, s->C, s->A, s->F, s->H), (hipStream_t)s->stream};

@@ -222,12 +222,7 @@ def gemm_batched_partial(As, Bs, M, N, K, lda, ldb):
     Cs = [torch.zeros((M, N), device=dev, dtype=torch.float32) for _ in range(n)]
     ws = torch.zeros((16 * 1024 * 1024,), device=dev, dtype=torch.float32)
     sk = ctypes.c_int(0)
-    fn = lib.drq_gemm_batched_partial
-    fn.restype = ctypes.c_int
-    fn.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_void_p, ctypes.c_long,
-                   ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]
-    check(fn(n, _ptr_array(As), lda, 1, _ptr_array(Bs), ldb, 1, _ptr_array(Cs), N, M, N, K, None, ptr(ws),
+    check(lib.drq_gemm_batched_partial(n, _ptr_array(As), lda, 1, _ptr_array(Bs), ldb, 1, _ptr_array(Cs), N, M, N, K, None, ptr(ws),
              ws.numel() * 4, ctypes.byref(sk), _stream()), "drq_gemm_batched_partial")
     k = sk.value
     if k <= 1:

@@ -7,7 +7,12 @@
  *   - plain pointers + sizes; every pointer is DEVICE memory owned by the caller (PyTorch-ROCm);
  *   - every call is enqueued on `stream` (a hipStream_t, passed as void*), nothing synchronises;
  *   - return 0 = ok, <0 = argument/shape/workspace error, >0 = hipError_t of the launch;
- *   - no global state, no allocation; tensors are fp32 row-major / NCHW unless stated.
+ *   - no allocation and no state that outlives a call, except two host-side caches indexed by the current HIP
+ *     device: the CU count, and "dynamic-LDS attribute already set" flags of the weight-gradient kernels;
+ *   - the library is built with -fvisibility=hidden: the functions declared here are ALL it exports
+ *     (tests/test_cpu_interface.py checks both directions); development ablations and time-stamp hooks exist only
+ *     in the -DDRQ_DEV build that tools/ makes for itself (drqv2_amd.build --dev -> libdrqv2_hip_dev.so);
+ *   - tensors are fp32 row-major / NCHW unless stated.
  */
 #ifndef DRQV2_HIP_H
 #define DRQV2_HIP_H
@@ -66,6 +71,14 @@ int drq_gemm_batched_f32(int nbatch, const float* const* A, long lda, int a_kc, 
                          int b_kc, float* const* C, long ldc, int M, int N, int K, const float* const* bias, int relu,
                          const float* const* aux, int ldaux, float* const* rowsum, int scatter_hw, int tile,
                          int splitk, float* ws, size_t ws_bytes, drq_stream_t stream);
+
+/* Forward form only (both operands k-contiguous, a_kc = b_kc = 1) with the split-K sum left to the caller: when
+ * *splitk_out > 1 the result is ws[(b*splitk + s)*M*N + m*N + n], s < splitk, WITHOUT bias (the consumer, e.g. the
+ * LayerNorm kernel of the trunk, sums the records and adds the bias itself); *splitk_out == 1: C holds the result
+ * with bias.  This is the entry DrQV2Agent.update uses for the trunk Linear(39200 -> feature_dim) (drqv2.py:74,100). */
+int drq_gemm_batched_partial(int nbatch, const float* const* A, long lda, int a_kc, const float* const* B, long ldb,
+                             int b_kc, float* const* C, long ldc, int M, int N, int K, const float* const* bias,
+                             float* ws, size_t ws_bytes, int* splitk_out, drq_stream_t stream);
 
 /* ---- output layer of the Q heads, nn.Linear(hidden, 1) (drqv2.py:106,111), nz (<= 8) problems per launch:
  * q = h w^T + b;  backward: dh = (dq w) * (h > 0), and if dw/db are given dw = dq^T h, db = sum dq. */
@@ -152,7 +165,9 @@ typedef struct {
   double lr, tau;
   float std, clip;
   long step_critic, step_enc, step_actor; /* 1-based Adam step numbers of THIS update */
-  float gscale;              /* 1/world_size when gradients were SUM-reduced, else 1 */
+  float gscale;              /* multiplies every gradient inside Adam.  The loss kernels already scale local
+                              * gradients by 1/global_B, so a SUM all-reduce needs gscale = 1 (what the host
+                              * passes); 1/world_size is only for hosts that feed per-rank MEAN gradients. */
   drq_stream_t stream;
   float* sums_host;          /* optional (may be NULL): device-visible pinned host memory, 16 floats.  As soon as
                               * sums[0..7] are final (after the actor loss, BEFORE the actor backward / Adam /

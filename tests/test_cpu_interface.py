@@ -156,6 +156,16 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert set(_lib.PROTOTYPES) == declared
     assert lib.drq_abi_version() == 3
+    # ... and the other direction: the product library exports NOTHING named drq* beyond the header (internal helpers
+    # have hidden visibility; the development hooks drq_dev_* exist only in the -DDRQ_DEV build of tools/)
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True)
+    exported = {ln.split()[-1] for ln in out.stdout.splitlines() if ln.strip()}
+    exported_drq = {n for n in exported if "drq" in n.lower()}
+    assert exported_drq == declared, sorted(exported_drq ^ declared)
+    # no environment knobs in the product library: update() cannot be steered onto an ablation by a stray variable
+    und = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True)
+    assert not any(ln.split()[-1].split("@")[0] in ("getenv", "secure_getenv") for ln in und.stdout.splitlines() if ln.strip())
     # layout entry points are host-only and callable without a GPU
     lay = _lib.param_layout(9, 6, 50, 1024)
     assert lay["seg"]["enc"][0] == 0 and lay["total"] == lay["seg"]["target"][1]

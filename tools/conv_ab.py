@@ -4,7 +4,7 @@ import ctypes, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from drqv2_amd import ops, _lib
-lib = _lib.load()
+lib = _lib.load(dev=True)   # -DDRQ_DEV build: python -m drqv2_amd.build --dev
 lib.drq_dev_conv_variant.argtypes = [ctypes.c_int]
 lib.drq_dev_conv_variant.restype = None
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 512

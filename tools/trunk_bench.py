@@ -16,7 +16,7 @@ for n in (4, 1):
     ts = []
     import ctypes
     from drqv2_amd import _lib
-    lib = _lib.load()
+    lib = _lib.load(dev=True)
     Cs = [torch.zeros((M, N), device="cuda") for _ in range(n)]
     wsb = torch.zeros((16 * 1024 * 1024,), device="cuda")
     skc = ctypes.c_int(0)

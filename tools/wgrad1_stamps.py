@@ -4,7 +4,7 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from drqv2_amd import ops, _lib
-lib = _lib.load()
+lib = _lib.load(dev=True)   # -DDRQ_DEV build: python -m drqv2_amd.build --dev
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 g = torch.Generator(device="cuda").manual_seed(0)
 x = torch.randn(nb, 9, 84, 84, device="cuda", generator=g)
