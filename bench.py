@@ -4,22 +4,29 @@ replay batches.  Contract: python bench.py --gpus N --steps K --warmup W  ->  ON
 
   step      = one DrQV2Agent.update(): aug x2, encoder fwd x2, critic loss+backward, Adam(critic, encoder),
               actor loss+backward, Adam(actor), Polyak; metrics fetched (use_tb=True) every update.
-  workload  = BASELINE.json configs[1]: cheetah_run, batch_size=256, 9x84x84 uint8 observations, A=6,
-              feature_dim=50, hidden_dim=1024, fp32.  N>1: one process per GPU (torch.distributed, RCCL),
-              every rank trains on its own 256-sample shard (weak scaling; --strong splits ONE 256 batch)
-              with two gradient all-reduces per update; value = batch-256 updates/sec of the whole job
-              = global samples/sec / 256.
-  roofline  = dominant kernel conv3x3_kernel<32,41,1> (conv2 forward on both views + conv3 dgrad),
-              timed live with events on the launch stream; algorithmic FLOPs = 2*32*288 per output pixel.
+  N = 1     workload = BASELINE.json configs[1]: cheetah_run, batch_size=256, 9x84x84 uint8 observations, A=6,
+              feature_dim=50, hidden_dim=1024, fp32 (`value`).  The line also carries `scaling_base`: the N=1
+              figure of the multi-GPU workload (configs[3], humanoid_run B=256), so the 1/2/4/8 curve has its
+              own first point.
+  N > 1     one process per GPU (torch.distributed, backend nccl = RCCL).  Started either by the driver
+              (torch.distributed.run: RANK/LOCAL_RANK/WORLD_SIZE in the environment) or by this script itself:
+              without WORLD_SIZE, `--gpus N` spawns N child ranks BEFORE anything touches the GPU and relays
+              rank 0's line.  Workload = BASELINE.json configs[3]: humanoid_run (A=21, feature_dim=100), ONE global
+              batch of 256 split N ways (`value`, "scaling": "strong"), two dependent gradient exchanges per update
+              hidden under compute.  The same line carries `weak` (256 samples PER GPU, value
+              = global samples/s / 256) and `n1_same_workload` (rank 0 alone on the plain single-GPU path, same
+              job, same box).  --workload / --task / --batch / --weak override.
+  roofline  = dominant kernel conv3x3_kernel<32,41,1> (conv2 forward on both views + conv3 dgrad), timed live
+              with events on the launch stream; algorithmic FLOPs = 2*32*288 per output pixel.
   cpu_baseline = the CPU oracle (oracle/drq_oracle.py, kind "port") on the host cores, rank 0, N=1 only.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -31,6 +38,7 @@ TASKS = {   # name: (A, feature_dim, lr, stddev_schedule)  -- cfgs/task/*.yaml o
     "cartpole_swingup": (1, 50, 1e-4, "linear(1.0,0.1,100000)"),
 }
 PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32 matrix == vector peak
+H = 1024
 
 
 def alg_flops_per_update(B, A, F, H=1024):
@@ -42,21 +50,28 @@ def alg_flops_per_update(B, A, F, H=1024):
     return B * (2 * E_f + E_b + 8 * T + 4 * P + 12 * Q)
 
 
-def main():
-    # stdout carries exactly one JSON line: anything else that writes to fd 1 (RCCL prints a version banner
-    # there at init, libdrm complains about amdgpu.ids) is sent to stderr, the line goes out on a private dup.
-    sys.stdout.flush()
-    json_out = os.fdopen(os.dup(1), "w")
-    os.dup2(2, 1)
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak) or global batch (--strong)")
-    ap.add_argument("--task", default="cheetah_run", choices=list(TASKS))
-    ap.add_argument("--strong", action="store_true", help="split ONE --batch over the GPUs")
+    ap.add_argument("--workload", default="auto", choices=["auto", "config2", "config4"],
+                    help="auto: config2 (cheetah_run B=256) on one GPU, config4 (humanoid_run, global B=256 split "
+                         "over the GPUs) on several")
+    ap.add_argument("--task", default=None, choices=list(TASKS), help="overrides the workload's task")
+    ap.add_argument("--batch", type=int, default=256, help="global batch (strong) or per-GPU batch (--weak)")
+    ap.add_argument("--weak", action="store_true", help="N>1: `value` is the weak-scaling run (--batch per GPU)")
+    ap.add_argument("--strong", action="store_true", help="N>1: split ONE --batch over the GPUs (the default)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "allreduce", "direct"],
+                    help="gradient exchange of the data-parallel path (drqv2_amd.engine.GradExchange)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="rehearsal only: gloo carries the CUDA tensors through the host, so that several ranks can "
+                         "share the single GPU of a development box (with --devices 0,0)")
+    ap.add_argument("--devices", default=None,
+                    help="rehearsal only: comma-separated device index per local rank (default: LOCAL_RANK)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip scaling_base / weak / n1_same_workload")
     ap.add_argument("--host-batch", action="store_true",
                     help="the replay iterator yields pinned HOST tensors (the reference boundary): every update "
                          "pays the H2D copy of its batch.  Reported for DESIGN.md section 6; never the headline value")
@@ -65,126 +80,246 @@ def main():
                          "instead of one fixed resident batch: the SURVEY 8f rank-2 path, reported in DESIGN.md")
     ap.add_argument("--dp-schedule", action="store_true",
                     help="development: run the data-parallel schedule on a one-rank RCCL group (N=1 only)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script as child processes.  The parent
+    has not touched (and never touches) the GPU; it does not re-exec itself.  Rank 0's stdout (the JSON line) is
+    relayed; the exit code is the first non-zero child code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        p.wait()
+        rc = rc or p.returncode
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return rc
+
+
+class Runner:
+    """One agent + one resident synthetic batch; times K updates the way the contract says."""
+
+    def __init__(self, task, B_local, B_global, dev, rank, world, dp, exchange="auto", host_batch=False,
+                 device_replay=False):
+        import torch
+        import drqv2
+        from drqv2_amd import synth
+        self.torch = torch
+        self.task, self.B_local, self.B_global, self.world, self.dp = task, B_local, B_global, world, dp
+        A, F, lr, sched = TASKS[task]
+        self.A, self.F = A, F
+        torch.manual_seed(1)
+        self.agent = drqv2.DrQV2Agent((9, 84, 84), (A,), dev, lr, F, H, 0.01, 2000, 2, sched, 0.3, True)
+        if dp:
+            self.agent.enable_data_parallel(batch_is_global=False, exchange=exchange)
+        batch = synth.make_batch(B_local, A, 9, seed=rank, smooth=True)
+        batch = tuple(t.pin_memory() for t in batch) if host_batch else tuple(t.to(dev) for t in batch)
+        self.batch = batch
+
+        def replay():
+            while True:
+                yield batch
+
+        self.it = replay()
+        if device_replay:
+            import numpy as np
+            from drqv2_amd.replay import DeviceReplay
+            store = DeviceReplay(4096, (9, 84, 84), A, 3, 0.99, dev, seed=rank)
+            obs_pool = batch[0].cpu().numpy()
+            r = np.random.RandomState(rank)
+            for e in range(16):                          # 16 episodes of 200 steps drawn from the synthetic frames
+                T1 = 201
+                store.add_episode({"observation": obs_pool[r.randint(0, obs_pool.shape[0], T1)],
+                                   "action": r.uniform(-1, 1, (T1, A)).astype(np.float32),
+                                   "reward": r.randn(T1, 1).astype(np.float32),
+                                   "discount": np.ones((T1, 1), np.float32)})
+            store.batch_size = B_local
+            self.it = iter(store)
+        self.step = 0
+
+    def sync(self):
+        if self.world > 1 and self.dp:
+            import torch.distributed as dist
+            dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def run(self, steps, warmup):
+        """W untimed updates, then exactly K timed ones bracketed by barrier + synchronize; MAX over ranks."""
+        torch = self.torch
+        ag = self.agent
+        for _ in range(warmup):
+            ag.update(self.it, self.step)
+            self.step += 2
+        ag.flush()
+        self.sync()
+        stamps = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            metrics = ag.update(self.it, self.step)
+            self.step += 2
+            stamps.append(time.perf_counter())       # update() returns when its metrics have left the GPU
+        ag.flush()         # data parallel: the last update's deferred Adam steps belong to the timed region
+        self.sync()
+        dt = time.perf_counter() - t0
+        per = sorted(1e3 * (b - a) for a, b in zip(stamps[:-1], stamps[1:]))
+        pct = (lambda q: per[min(len(per) - 1, int(q * len(per)))]) if per else (lambda q: None)
+        if self.world > 1 and self.dp:
+            import torch.distributed as dist
+            t = torch.tensor([dt], device=ag._engine.device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return {"value": steps * (self.B_global / 256.0) / dt, "ms_per_step": 1e3 * dt / steps,
+                "ms_per_step_p10_p50_p90": [pct(0.1), pct(0.5), pct(0.9)], "ms_per_step_max": per[-1] if per else None,
+                "dt": dt, "last_metrics": metrics}
+
+    def describe(self):
+        return (f"{self.task} batch_size={self.B_local}/GPU ({self.B_global} global) 9x84x84 u8 obs, A={self.A}, "
+                f"feature_dim={self.F}, hidden_dim={H}, fp32, use_tb=True")
+
+    def close(self):
+        self.agent.flush()
+        self.torch.cuda.synchronize()
+        self.agent = None
+        self.batch = None
+        self.it = None
+        self.torch.cuda.empty_cache()
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args)          # nothing above this line has initialised the GPU
+
+    # stdout carries exactly one JSON line: anything else that writes to fd 1 (RCCL prints a version banner
+    # there at init, libdrm complains about amdgpu.ids) is sent to stderr, the line goes out on a private dup.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dev_index = int(args.devices.split(",")[local_rank]) if args.devices else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     use_dp = world > 1 or args.dp_schedule
     if use_dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            args.exchange = "allreduce"        # gloo has no all-to-all for device tensors
 
-    import drqv2
-    from drqv2_amd import synth
-
-    A, F, lr, sched = TASKS[args.task]
-    H = 1024
-    B_local = args.batch // world if args.strong else args.batch
+    workload = args.workload if args.workload != "auto" else ("config2" if world == 1 else "config4")
+    task = args.task or ("cheetah_run" if workload == "config2" else "humanoid_run")
+    strong = world > 1 and not args.weak
+    if strong and args.batch % world:
+        raise SystemExit(f"--batch {args.batch} does not split over {world} GPUs")
+    B_local = args.batch // world if strong else args.batch
     B_global = B_local * world
-    torch.manual_seed(1)
-    agent = drqv2.DrQV2Agent((9, 84, 84), (A,), dev, lr, F, H, 0.01, 2000, 2, sched, 0.3, True)
-    if use_dp:
-        agent.enable_data_parallel(batch_is_global=False)
-    batch = synth.make_batch(B_local, A, 9, seed=rank, smooth=True)
-    batch = tuple(t.pin_memory() for t in batch) if args.host_batch else tuple(t.to(dev) for t in batch)
+    A, F, _, _ = TASKS[task]
 
-    def replay():
-        while True:
-            yield batch
-
-    it = replay()
-    if args.device_replay:
-        import numpy as np
-        from drqv2_amd.replay import DeviceReplay
-        store = DeviceReplay(4096, (9, 84, 84), A, 3, 0.99, dev, seed=rank)
-        obs_pool = batch[0].cpu().numpy()
-        r = np.random.RandomState(rank)
-        for e in range(16):                          # 16 episodes of 200 steps drawn from the synthetic frames
-            T1 = 201
-            store.add_episode({"observation": obs_pool[r.randint(0, obs_pool.shape[0], T1)],
-                               "action": r.uniform(-1, 1, (T1, A)).astype(np.float32),
-                               "reward": r.randn(T1, 1).astype(np.float32),
-                               "discount": np.ones((T1, 1), np.float32)})
-        store.batch_size = B_local
-        it = iter(store)
-    step = 0
-    for _ in range(args.warmup):
-        agent.update(it, step)
-        step += 2
-    agent.flush()
-
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    sync()
-    stamps = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        metrics = agent.update(it, step)
-        step += 2
-        stamps.append(time.perf_counter())       # update() returns when its metrics have left the GPU
-    agent.flush()          # data parallel: the last update's deferred Adam(actor) belongs to the timed region
-    sync()
-    dt = time.perf_counter() - t0
-    per = sorted(1e3 * (b - a) for a, b in zip(stamps[:-1], stamps[1:]))
-    pct = (lambda q: per[min(len(per) - 1, int(q * len(per)))]) if per else (lambda q: None)
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    value = args.steps * (B_global / 256.0) / dt
+    main_run = Runner(task, B_local, B_global, dev, rank, world, use_dp, args.exchange, args.host_batch,
+                      args.device_replay)
+    res = main_run.run(args.steps, args.warmup)
+    dt = res.pop("dt")
     out = {
-        "metric": "agent updates/sec (batch=256, 9x84x84 obs)", "value": value, "unit": "updates/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-        "ms_per_step_p10_p50_p90": [pct(0.1), pct(0.5), pct(0.9)],
-        "ms_per_step_max": per[-1] if per else None,
-        "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+        "metric": "agent updates/sec (batch=256, 9x84x84 obs)", "value": res["value"], "unit": "updates/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+        "ms_per_step_p10_p50_p90": res["ms_per_step_p10_p50_p90"], "ms_per_step_max": res["ms_per_step_max"],
+        "higher_is_better": True, "scaling": "strong" if (strong or world == 1) else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic" + (" (batch copied host->device every update)" if args.host_batch else "")
                                 + (" (batches assembled by the device replay)" if args.device_replay else ""),
-        "config": {"workload": f"{args.task} batch_size={B_local}/GPU ({B_global} global) 9x84x84 u8 obs, A={A}, "
-                               f"feature_dim={F}, hidden_dim={H}, fp32, use_tb=True",
-                   "parallelism": f"dp{world}", "global_batch": B_global},
+        "config": {"workload": main_run.describe(), "parallelism": f"dp{world}", "global_batch": B_global,
+                   "backend": ("rccl" if args.backend == "nccl" else "gloo (rehearsal)") if use_dp else None,
+                   "baseline_config": {"config2": 1, "config4": 3}[workload] if args.task is None else None},
         "alg_gflop_per_update": alg_flops_per_update(B_global, A, F, H) / 1e9,
         "frac_fp32_peak_whole_step": alg_flops_per_update(B_global, A, F, H) * args.steps / dt /
                                      (PEAK_FP32_TFLOPS * 1e12 * world),
-        "last_metrics": metrics,
+        "last_metrics": res["last_metrics"],
     }
+    if use_dp and main_run.agent._engine.exchange is not None:
+        ex = main_run.agent._engine.exchange
+        out["exchange"] = {"mode": ex.mode, "choice_by_bucket_floats": {str(k): v for k, v in ex.choice.items()},
+                           "measured_us_by_bucket_floats": {str(k): v for k, v in ex.timings_us.items()}}
 
     if not args.no_roofline:
         # every rank runs it (the updates inside carry the data-parallel collectives); rank 0 reports
-        roof = roofline_conv(agent, B_local, it, step)
-        agent.flush()
+        roof = roofline_conv(main_run.agent, B_local, main_run.it, main_run.step)
+        main_run.agent.flush()
         if rank == 0:
             out["roofline"] = roof
+    main_run.close()
+
+    extras = not (args.no_extras or args.host_batch or args.device_replay or args.dp_schedule)
+    k2, w2 = max(20, args.steps // 2), max(5, args.warmup // 2)
+    if extras and world == 1 and workload == "config2" and args.task is None:
+        # first point of the configs[3] scaling curve, on the same box in the same run
+        r = Runner("humanoid_run", args.batch, args.batch, dev, 0, 1, False)
+        rr = r.run(k2, w2)
+        out["scaling_base"] = {"workload": r.describe(), "value": rr["value"], "ms_per_step": rr["ms_per_step"],
+                               "steps": k2, "warmup": w2, "n_gpus": 1,
+                               "note": "N=1 of BASELINE configs[3] (humanoid_run, global batch 256): the workload "
+                                       "`value` is quoted on when --gpus > 1"}
+        r.close()
+    if extras and world > 1:
+        import torch.distributed as dist
+        if strong:
+            # weak scaling beside it: --batch samples on EVERY GPU
+            r = Runner(task, args.batch, args.batch * world, dev, rank, world, True, args.exchange)
+            rr = r.run(k2, w2)
+            out["weak"] = {"scaling": "weak", "workload": r.describe(), "value": rr["value"],
+                           "ms_per_step": rr["ms_per_step"], "steps": k2, "warmup": w2, "global_batch": args.batch * world,
+                           "note": "value = global samples/s / 256 (batch-256 equivalents)"}
+            r.close()
+        # the same global batch on ONE GPU through the plain (non-data-parallel) path: rank 0 alone, others wait
+        if rank == 0:
+            r = Runner(task, B_global if strong else B_local, B_global if strong else B_local, dev, 0, 1, False)
+            rr = r.run(k2, w2)
+            out["n1_same_workload"] = {"workload": r.describe(), "value": rr["value"], "ms_per_step": rr["ms_per_step"],
+                                       "steps": k2, "warmup": w2}
+            r.close()
+        dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.task, B_local)
+        out["cpu_baseline"] = cpu_baseline(task, B_local)
     if rank == 0:
         print(json.dumps(out), file=json_out, flush=True)
     if use_dp:
+        import torch.distributed as dist
         if world > 1:
             dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
-# HBM-side bytes per launch of the two launches of conv3x3_kernel<32,41,1> at B = 256, from separate rocprofv3
-# --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (profiles/r01_conv_traffic_pmc.txt, tools/pmc_traffic.sh):
-# (2 * FETCH_SIZE + WRITE_SIZE) * 1024, the factor 2 being the guide's gfx950 correction of FETCH_SIZE.
-CONV_TRAFFIC_KB_B256 = {"conv2_fwd_2B": (68048.2, 106558.5), "conv3_dgrad_B": (63133.0, 54238.4)}
-TRAFFIC_NOTE = ("bytes per launch, mean of the two launches, (2*FETCH_SIZE+WRITE_SIZE)*1024 from separate --pmc passes "
-                "at B=256 (profiles/r01_conv_traffic_pmc.txt); algorithmic bytes are 210 MB (fwd) / 155 MB (dgrad); the "
-                "x2 on FETCH_SIZE is calibrated for 16-byte lane loads, this kernel uses 12-byte ones: the uncorrected "
-                "sum is 179 / 120 MB")
+def conv_traffic():
+    """HBM-side bytes per launch of the two launches of conv3x3_kernel<32,41,1> at B = 256, as measured by
+    tools/pmc_traffic.sh (separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes) and written, with the commit
+    it was measured at, to profiles/conv_traffic.json.  None when that file is missing."""
+    path = os.path.join(ROOT, "profiles", "conv_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
 
 
 def roofline_conv(agent, B, it, step):
@@ -193,6 +328,7 @@ def roofline_conv(agent, B, it, step):
     (DrqStep.timing_events).  In isolation, back to back, the same launches run ~10 % slower (the chip holds a
     lower clock under an MFMA-only load than inside the update's mix of kernels), and rocprofv3's per-kernel
     average of the bench agrees with the in-update figure, not with the isolated one."""
+    import torch
     eng = agent._engine
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     for e in ev:
@@ -213,22 +349,28 @@ def roofline_conv(agent, B, it, step):
         eng.set_timing_events(None)
     t_f /= n
     t_d /= n
-    traffic = None
-    if B == 256:
-        traffic = sum((2 * f + w) * 1024 for f, w in CONV_TRAFFIC_KB_B256.values()) / len(CONV_TRAFFIC_KB_B256)
+    traffic, note = None, None
+    tr = conv_traffic()
+    if tr is not None and B == tr.get("B"):
+        per = [(2 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024 for v in tr["launches"].values()]
+        traffic = sum(per) / len(per)
+        note = (f"bytes per launch, mean of the two launches, (2*FETCH_SIZE+WRITE_SIZE)*1024 from separate --pmc passes at "
+                f"B={tr['B']} (profiles/conv_traffic.json, measured at commit {tr.get('commit')}); algorithmic bytes are "
+                "210 MB (fwd) / 155 MB (dgrad); the x2 on FETCH_SIZE is calibrated for 16-byte lane loads, this kernel "
+                "uses 12-byte ones")
     fl_f = 2 * 32 * 288 * (2 * B) * 39 * 39
     fl_d = 2 * 32 * 288 * B * 39 * 39
     ach = (fl_f + fl_d) / (t_f + t_d) / 1e12
     return {"kernel": "conv3x3_kernel<32,41,1>", "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS,
-            "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "traffic": traffic,
-            "traffic_note": TRAFFIC_NOTE if traffic is not None else None,
+            "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_note": note,
             "avg_launch_us": 0.5e6 * (t_f + t_d), "launch_us": {"conv2_fwd_2B": 1e6 * t_f, "conv3_dgrad_B": 1e6 * t_d},
-            "alg_gflop_per_launch": {"conv2_fwd_2B": fl_f / 1e9, "conv3_dgrad_B": fl_d / 1e9},
+            "alg_gflop_per_launch": {"conv2_fwd_2B": fl_f / 1e9, "conv3_dgrad_B": fl_d / 1e9}, "frames_per_launch": B,
             "timing": "hipEvent pairs recorded by the library around the two launches inside 20 update() calls"}
 
 
 def cpu_baseline(task, B):
     """The CPU oracle timed on the host cores: same workload, bounded sample (2 warm-up + 4 timed updates)."""
+    import torch
     from drqv2_amd import synth
     from oracle import drq_oracle as O
     A, F, lr, sched = TASKS[task]
@@ -254,4 +396,4 @@ def cpu_baseline(task, B):
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

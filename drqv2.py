@@ -163,12 +163,14 @@ class DrQV2Agent:
         return action.cpu().numpy()[0]
 
     # ---- data parallel (new: one process per GPU, RCCL all-reduce of the flat gradient arenas) ---
-    def enable_data_parallel(self, process_group=None, batch_is_global=True, global_metrics=False):
+    def enable_data_parallel(self, process_group=None, batch_is_global=True, global_metrics=False,
+                             exchange="allreduce"):
         """batch_is_global: every rank's replay_iter yields the same global batch and this rank trains
         on its contiguous slice; otherwise the iterator already yields this rank's shard.
         global_metrics: the returned metrics are means over the GLOBAL batch (one more 32-byte all-reduce per
-        update); by default they are the means over this rank's shard (the gradients are always global)."""
-        self._engine.enable_data_parallel(process_group, global_metrics)
+        update); by default they are the means over this rank's shard (the gradients are always global).
+        exchange: "allreduce" | "direct" | "auto" -- drqv2_amd.engine.GradExchange."""
+        self._engine.enable_data_parallel(process_group, global_metrics, exchange)
         self._batch_is_global = batch_is_global
 
     def _draws(self, n_global, A):

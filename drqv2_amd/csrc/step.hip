@@ -50,6 +50,9 @@ namespace {
 
 constexpr long R = 32L * 35 * 35;   // repr_dim (drqv2.py:53)
 inline long al64(long x) { return (x + 63) & ~63L; }
+// segment (= optimiser / exchange bucket) boundaries: multiples of 512 floats, so that every bucket splits into
+// 2, 4 or 8 equal slices of whole 64-float lines (reduce-scatter style exchanges, sharded optimiser steps)
+inline long al512(long x) { return (x + 511) & ~511L; }
 
 struct HeadOff {
   long trunk_w, trunk_b, ln_g, ln_b;
@@ -79,6 +82,7 @@ ParamLayout param_layout(int C, int A, int F, int H) {
     L.enc_w[l] = take(32L * (l == 0 ? C : 32) * 9);
     L.enc_b[l] = take(32);
   }
+  off = al512(off);
   L.seg[1] = off;
   auto head = [&](HeadOff& h, int nq, int in_extra, int out_last) {
     h.trunk_w = take((long)F * R);
@@ -96,12 +100,15 @@ ParamLayout param_layout(int C, int A, int F, int H) {
   };
   L.seg[2] = off;
   head(L.critic, 2, A, 1);
+  off = al512(off);
   L.seg[3] = off;
   L.seg[4] = off;
   head(L.actor, 1, 0, A);
+  off = al512(off);
   L.seg[5] = off;
   L.seg[6] = off;
   head(L.target, 2, A, 1);
+  off = al512(off);
   L.seg[7] = off;
   L.total = off;
   L.nflat = nf;

@@ -77,11 +77,138 @@ def grad_buckets_overlap(layout):
     return tuple((seg[k][0], seg[k][1]) for k in ("critic", "enc", "actor"))
 
 
+class _StreamWork:
+    """Handle of an exchange that runs on a side stream: wait() makes the CURRENT stream wait for it (like the
+    Work objects of torch.distributed on RCCL), never the host."""
+
+    def __init__(self, stream, keep=None):
+        self.stream, self.keep = stream, keep
+
+    def wait(self):
+        torch.cuda.current_stream(self.stream.device).wait_stream(self.stream)
+        self.keep = None
+
+
+class GradExchange:
+    """SUM of a contiguous range of the gradient arena over the ranks, in place, asynchronously.
+
+    allreduce  one all-reduce per bucket (RCCL chooses ring / tree / its own direct algorithms).
+    direct     two-phase exchange sized for a fully connected xGMI node: the bucket is cut
+               into `world` equal slices; an all-to-all hands rank r the `world` copies of slice r (every rank talks
+               to its world-1 peers at once: all links carry 1/world of the bucket instead of a ring pushing
+               (world-1)/world of it through each hop); rank r adds them in rank order (the same order on every
+               rank: bit-identical results everywhere); an all-gather returns the reduced slices.  Needs the
+               bucket length to divide by world*64 floats (segments are padded to 512 floats: world 2, 4, 8).
+    auto       times both on scratch copies of the real buckets at enable time (max over ranks) and keeps the faster
+               per bucket -- which one wins depends on the bucket size and the RCCL build, and this repository's
+               CI box has one GPU, so the choice is made where the job runs, by measurement."""
+
+    MODES = ("allreduce", "direct", "auto")
+
+    def __init__(self, pg, world, device, mode="allreduce"):
+        if mode not in self.MODES:
+            raise ValueError(f"exchange mode {mode!r}: one of {self.MODES}")
+        self.pg, self.world, self.device = pg, world, torch.device(device)
+        self.mode = mode
+        self.choice = {}          # bucket length -> "allreduce" | "direct"  (auto)
+        self.timings_us = {}      # bucket length -> {"allreduce": us, "direct": us}
+        self._side = None
+        self._scratch = {}
+
+    def direct_ok(self, n):
+        return self.world > 1 and n % (self.world * 64) == 0
+
+    def _bufs(self, n):
+        b = self._scratch.get(n)
+        if b is None:
+            b = (torch.empty(n, device=self.device, dtype=torch.float32),
+                 torch.empty(n // self.world, device=self.device, dtype=torch.float32))
+            self._scratch[n] = b
+        return b
+
+    def _direct(self, t):
+        """Runs on the current stream (the callers put it on a side stream)."""
+        import torch.distributed as dist
+        n = t.numel()
+        recv, red = self._bufs(n)
+        dist.all_to_all_single(recv, t, group=self.pg)                    # recv[j] = rank j's copy of MY slice
+        torch.sum(recv.view(self.world, n // self.world), dim=0, out=red)  # fixed (rank) order
+        dist.all_gather_into_tensor(t, red, group=self.pg)
+
+    def _pick(self, n):
+        if self.mode == "allreduce" or not self.direct_ok(n):
+            return "allreduce"
+        if self.mode == "direct":
+            return "direct"
+        return self.choice.get(n, "allreduce")
+
+    def start(self, t):
+        """Begin SUM(t) over the ranks once the work queued so far on the current stream has produced t; returns
+        a handle whose wait() orders the current stream after the exchange."""
+        import torch.distributed as dist
+        if self._pick(t.numel()) == "allreduce":
+            return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        if self.device.type != "cuda":
+            self._direct(t)
+            return _Done()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        side = self._side
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            self._direct(t)
+        return _StreamWork(side, t)
+
+    def calibrate(self, lengths, iters=20, warmup=5):
+        """auto: time both strategies for each bucket length on scratch tensors; all ranks agree on the result
+        (MAX over ranks of the per-exchange time)."""
+        import time
+        import torch.distributed as dist
+        for n in sorted(set(lengths)):
+            if not self.direct_ok(n):
+                self.choice[n] = "allreduce"
+                continue
+            t = torch.zeros(n, device=self.device, dtype=torch.float32)
+            res = {}
+            for name in ("allreduce", "direct"):
+                fn = (lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)) if name == "allreduce" \
+                    else (lambda: self._direct(t))
+                for _ in range(warmup):
+                    fn()
+                if self.device.type == "cuda":
+                    torch.cuda.synchronize(self.device)
+                dist.barrier(group=self.pg)
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    fn()
+                if self.device.type == "cuda":
+                    torch.cuda.synchronize(self.device)
+                dt = torch.tensor([(time.perf_counter() - t0) / iters * 1e6], device=self.device, dtype=torch.float64)
+                dist.all_reduce(dt, op=dist.ReduceOp.MAX, group=self.pg)
+                res[name] = float(dt.item())
+            self.timings_us[n] = res
+            self.choice[n] = min(res, key=res.get)
+        return self.choice
+
+
+class _Done:
+    def wait(self):
+        return None
+
+
 class StepEngine:
     def __init__(self, encoder, actor, critic, critic_target, obs_shape, action_dim, feature_dim, hidden_dim, lr,
                  device):
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
         self.C, self.A, self.F, self.H = int(obs_shape[0]), int(action_dim), int(feature_dim), int(hidden_dim)
+        # what the kernels are instantiated for (check_step in csrc/step.hip): said here, not at the first launch
+        if self.C != 9 or tuple(obs_shape[1:]) != (84, 84):
+            raise _lib.DrqError(f"obs_shape {tuple(obs_shape)}: the HIP encoder is built for (9, 84, 84) "
+                                "(frame_stack=3, cfgs/config.yaml:7)")
+        if not (0 < self.F <= 256) or self.A <= 0 or self.H <= 0:
+            raise _lib.DrqError(f"feature_dim={self.F} (1..256), action_dim={self.A}, hidden_dim={self.H}: unsupported")
         self.layout = _lib.param_layout(self.C, self.A, self.F, self.H)
         total = self.layout["total"]
         dev = self.device
@@ -115,6 +242,7 @@ class StepEngine:
         self._side_busy = False
         self.world = 1
         self.rank = 0
+        self.exchange = None      # GradExchange (enable_data_parallel)
 
     # ---- arenas --------------------------------------------------------------------------
     def _adopt(self, name, mod):
@@ -161,22 +289,22 @@ class StepEngine:
         return self._base
 
     # ---- data parallel -------------------------------------------------------------------
-    def enable_data_parallel(self, process_group=None, global_metrics=False):
+    def enable_data_parallel(self, process_group=None, global_metrics=False, exchange="allreduce"):
+        """exchange: how the gradient buckets are summed over the ranks (GradExchange): "allreduce", "direct" or
+        "auto" (measures both on the real bucket sizes now and keeps the faster)."""
         import torch.distributed as dist
         self.global_metrics = bool(global_metrics)
         self.pg = process_group if process_group is not None else dist.group.WORLD
         self.world = dist.get_world_size(self.pg)
         self.rank = dist.get_rank(self.pg)
-
-    def _allreduce(self, t):
-        import torch.distributed as dist
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+        self.exchange = GradExchange(self.pg, self.world, self.device, exchange)
+        if exchange == "auto" and self.world > 1:
+            self.exchange.calibrate([e - b for b, e in grad_buckets_overlap(self.layout)])
 
     def _allreduce_async(self, t):
-        """SUM all-reduce that starts once the work queued so far has produced `t` and runs beside what is
+        """SUM over the ranks that starts once the work queued so far has produced `t` and runs beside what is
         queued next (RCCL: its own stream; .wait() makes the current stream wait, not the host)."""
-        import torch.distributed as dist
-        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        return self.exchange.start(t)
 
     def set_timing_events(self, events):
         """bench.py instrumentation: 4 torch.cuda.Event(enable_timing=True), each recorded once already (so that
@@ -192,8 +320,14 @@ class StepEngine:
             self._side = torch.cuda.Stream(device=self.device)
         return self._side
 
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
     def _phase(self, desc, k):
-        check(_lib.load().drq_update_phase(ctypes.byref(desc), k), f"drq_update_phase({k})")
+        # the library launches on the CURRENT HIP device: make that the agent's (an agent on cuda:1 in a process
+        # whose current device is 0 would otherwise launch device-1 pointers on device 0)
+        with torch.cuda.device(self.device):
+            check(_lib.load().drq_update_phase(ctypes.byref(desc), k), f"drq_update_phase({k})")
 
     def flush_encoder(self):
         """Data parallel: the deferred Adam(encoder) of the last update (phase 8).  Before the encoder is read."""
@@ -203,7 +337,7 @@ class StepEngine:
         self._pending_enc = None
         work.wait()
         if self.device.type == "cuda":
-            desc.stream = torch.cuda.current_stream().cuda_stream
+            desc.stream = self._stream()
         self._phase(desc, 8)
         del keep
 
@@ -218,7 +352,7 @@ class StepEngine:
         self._pending = None
         work.wait()
         if self.device.type == "cuda":
-            desc.stream = torch.cuda.current_stream().cuda_stream
+            desc.stream = self._stream()
         self._phase(desc, 9)
         del keep
 
@@ -239,7 +373,7 @@ class StepEngine:
         # local gradients are already scaled by 1/global_B (drq_td_mse / drq_actor_loss), so the SUM
         # all-reduce over ranks yields the global-batch mean gradient: no further scaling
         d.gscale = 1.0
-        d.stream = torch.cuda.current_stream().cuda_stream
+        d.stream = self._stream()
         d.sums_host = ptr(self.sums_host) if (self.pg is None and self.sums_host is not None) else None
         d.timing_events = self._timing_array      # None, or 4 hipEvent_t for bench.py's roofline
         return d
@@ -248,6 +382,10 @@ class StepEngine:
                clip, tau, B_global=None):
         """All tensors are this rank's shard, on the GPU.  Returns the 8-float sums tensor (device)."""
         B = obs.shape[0]
+        for nm, t in (("obs", obs), ("next_obs", next_obs)):
+            if t.dtype != torch.uint8 or tuple(t.shape) != (B, self.C, 84, 84) or not t.is_contiguous():
+                raise _lib.DrqError(f"update(): {nm} must be contiguous uint8 [{B},{self.C},84,84] "
+                                    f"(replay_buffer.py:185-189), got {t.dtype} {tuple(t.shape)}")
         B_global = B * self.world if B_global is None else B_global
         steps = (self.critic_opt.begin_step(), self.encoder_opt.begin_step(), self.actor_opt.begin_step())
         d = self.make_desc(B, B_global, std, clip, tau, steps)
@@ -268,7 +406,7 @@ class StepEngine:
             mirror = self.sums_host is not None
             seq = steps[2] & 0xFFFFFFFF
             if self._side_busy:                                 # the previous update's sums exchange owns self.sums
-                torch.cuda.current_stream().wait_stream(self._side)
+                torch.cuda.current_stream(self.device).wait_stream(self._side)
                 self._side_busy = False
             self.flush_encoder()                                # previous update's Adam(encoder)
             self._phase(d, 3)                                   # aug + encoder forward: no actor weights yet
@@ -287,7 +425,7 @@ class StepEngine:
                 # global metric sums: reduced and published beside phase 7 (a side stream, so that the 32-byte
                 # exchange's latency is not inserted between phases 6 and 7)
                 if self.device.type == "cuda":
-                    main = torch.cuda.current_stream()
+                    main = torch.cuda.current_stream(self.device)
                     side = self._side_stream()
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
@@ -331,11 +469,17 @@ class StepEngine:
 
     def act_forward(self, obs_u8):
         """obs u8 [n,C,84,84] on the GPU -> mu [n,A]."""
+        if obs_u8.dtype != torch.uint8 or not obs_u8.is_cuda or obs_u8.device != self.device:
+            raise _lib.DrqError(f"act(): uint8 frames on {self.device} required (dmc.py:79-84 yields uint8), got "
+                                f"{obs_u8.dtype} on {obs_u8.device}")
+        if tuple(obs_u8.shape[1:]) != (self.C, 84, 84):
+            raise _lib.DrqError(f"act(): frames of shape {(self.C, 84, 84)} required, got {tuple(obs_u8.shape[1:])}")
         self.flush()
         lib = _lib.load()
         n = obs_u8.shape[0]
         B = self._ws_B if (self._ws_B is not None and 2 * self._ws_B >= n) else max(1, (n + 1) // 2)
         d = self.make_desc(B, B, 1.0, 0.0, 0.0, (1, 1, 1))
         mu = torch.empty((n, self.A), device=self.device, dtype=torch.float32)
-        check(lib.drq_act_forward(ctypes.byref(d), ptr(obs_u8), n, ptr(mu)), "drq_act_forward")
+        with torch.cuda.device(self.device):
+            check(lib.drq_act_forward(ctypes.byref(d), ptr(obs_u8), n, ptr(mu)), "drq_act_forward")
         return mu

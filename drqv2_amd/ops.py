@@ -15,6 +15,10 @@ def _stream():
 def _need(t, dtype=torch.float32, name="tensor"):
     if not (isinstance(t, torch.Tensor) and t.is_cuda):
         raise _lib.DrqError(f"{name}: a GPU tensor is required (the HIP path has no CPU fallback)")
+    if t.device.index != torch.cuda.current_device():
+        # these wrappers launch on the current device's current stream (the update path guards the device itself)
+        raise _lib.DrqError(f"{name} lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}: "
+                            "wrap the call in torch.cuda.device(...)")
     if t.dtype != dtype or not t.is_contiguous():
         raise _lib.DrqError(f"{name}: contiguous {dtype} required, got {t.dtype} contiguous={t.is_contiguous()}")
     return t

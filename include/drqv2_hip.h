@@ -183,7 +183,8 @@ typedef struct {
 } DrqStep;
 
 /* Parameter arena: tensors in parameters() order of encoder, critic, actor, critic_target, each start
- * aligned to 64 floats.  out[] receives, in this order: encoder 8 offsets, critic 16, actor 10,
+ * aligned to 64 floats, each network's segment padded to a multiple of 512 floats (a segment is one optimiser
+ * launch and one data-parallel exchange bucket: it splits into 2/4/8 equal slices of whole lines).  out[] receives, in this order: encoder 8 offsets, critic 16, actor 10,
  * critic_target 16, then [enc_beg, enc_end, critic_beg, critic_end, actor_beg, actor_end, target_beg,
  * target_end], then total.  Returns the number of longs written (59) or <0. */
 int drq_param_layout(int C, int A, int F, int H, long* out, int cap);

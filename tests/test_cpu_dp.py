@@ -177,6 +177,59 @@ def test_overlapped_schedule_order_and_deferred_actor_step():
     assert enc[1] <= crit[0] and crit[1] <= act[0]
 
 
+def _exchange_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from drqv2_amd import _lib
+        from drqv2_amd.engine import GradExchange, grad_buckets_overlap
+        lay = _lib.param_layout(9, 6, 50, 1024)
+        out = {}
+        for (b, e) in grad_buckets_overlap(lay):
+            n = e - b
+            assert n % 512 == 0                      # every bucket splits evenly over 2, 4, 8 ranks
+            g = torch.Generator().manual_seed(100 + rank)
+            x = torch.randn(n, generator=g)
+            want = x.clone()
+            dist.all_reduce(want, op=dist.ReduceOp.SUM)
+            ex = GradExchange(dist.group.WORLD, world, "cpu", "direct")
+            assert ex.direct_ok(n)
+            y = x.clone()
+            ex.start(y).wait()
+            # two ranks: a + b in either order is the same float; the direct result is also identical on all ranks
+            assert torch.equal(y, want), (rank, n)
+            both = [torch.empty_like(y) for _ in range(world)]
+            dist.all_gather(both, y)
+            assert torch.equal(both[0], both[1])
+            ex2 = GradExchange(dist.group.WORLD, world, "cpu", "auto")
+            choice = ex2.calibrate([n], iters=2, warmup=1)
+            assert choice[n] in ("allreduce", "direct") and set(ex2.timings_us[n]) == {"allreduce", "direct"}
+            z = x.clone()
+            ex2.start(z).wait()
+            assert torch.equal(z, want)
+            out[n] = choice[n]
+        # a length that does not split falls back to the all-reduce
+        ex = GradExchange(dist.group.WORLD, world, "cpu", "direct")
+        odd = torch.ones(8)
+        assert not ex.direct_ok(8)
+        ex.start(odd).wait()
+        assert torch.equal(odd, torch.full((8,), float(world)))
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+def test_direct_exchange_equals_allreduce_world2():
+    """GradExchange 'direct' (all-to-all of slices, rank-order sum, all-gather) on the real bucket sizes of the
+    cheetah layout equals the all-reduce, is identical on every rank, and 'auto' picks the same mode everywhere."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_exchange_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert sorted(ret.keys()) == [0, 1] and ret[0] == ret[1]
+
+
 def test_shard_bounds():
     from drqv2_amd.engine import shard_bounds
     assert shard_bounds(256, 1, 0, True) == (0, 256, 256)

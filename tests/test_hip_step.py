@@ -58,6 +58,76 @@ def run_hip(ag, cfg, u):
     return m, batch, draws
 
 
+def check_encoder_inputs_bitwise(ag, cfg, batch, sh_o, sh_n):
+    """The in-step aug + /255-0.5 buffer (both views, the stacked launch the update really issues) against the
+    oracle's RandomShiftsAug restatement: every element identical.  Returns the buffer on the CPU."""
+    from oracle import drq_oracle as O
+    B = cfg["B"]
+    base = O.aug_base_grid(84, 4)
+    xin = ag._engine.ws_view("AUG", B, (2 * B, cfg["C"], 84, 84)).cpu()
+    for view, frames, sh in ((xin[:B], batch[0], sh_o), (xin[B:], batch[4], sh_n)):
+        want = O.random_shifts_aug(frames.float(), sh, 4, base) / 255.0 - 0.5
+        ndiff = int((view != want).sum())
+        assert ndiff == 0, (ndiff, float((view - want).abs().max()))
+    return xin
+
+
+def check_relu_decisions(ag, cfg, o64, xin_obs):
+    """Run the fp64 oracle's OWN encoder (its own ReLU decisions) on the obs view and compare every ReLU decision
+    of the HIP encoder with it.  A disagreement is only legitimate where fp32 cannot decide the sign: the fp64
+    pre-activation must lie inside the fp32 forward-error bound of its own dot product,
+    |pre| <= 4 * gamma_n * (|w| * |x| + |b|), gamma_n = n*2^-24, n = 9*Cin+1 (the factor 4 covers the
+    rounding already carried by the layer's inputs).  The number of such units is bounded too.
+    Returns (#disagreements, #units)."""
+    import torch.nn.functional as Fn
+    B = cfg["B"]
+    eng = ag._engine
+    hs = (41, 39, 37, 35)
+    hip = [eng.ws_view(nm, B, (2 * B, 32, h, h))[:B].cpu() for nm, h in zip(("ACT1", "ACT2", "ACT3"), hs)]
+    hip.append(eng.ws_view("FEAT", B, (2 * B, 32, 35, 35))[:B].cpu())
+    from oracle import drq_oracle as O
+    feat, acts = O.encoder_forward(o64.enc, xin_obs.double(), return_acts=True, normalized=True)
+    flips = total = 0
+    for li, i in enumerate((0, 2, 4, 6)):
+        w, b = o64.enc[f"convnet.{i}.weight"], o64.enc[f"convnet.{i}.bias"]
+        st = 2 if li == 0 else 1
+        pre = Fn.conv2d(acts[li], w, b, stride=st)
+        dis = (pre > 0) != (hip[li] > 0)
+        n = int(dis.sum())
+        total += pre.numel()
+        if n:
+            mag = Fn.conv2d(acts[li].abs(), w.abs(), b.abs(), stride=st)
+            gamma = (9 * w.shape[1] + 1) * 2.0 ** -24
+            worst = float((pre.abs()[dis] / (4 * gamma * mag[dis])).max())
+            assert worst <= 1.0, (li, n, worst)
+            # where the HIP side says "on", the value it kept is rounding-sized as well
+            assert float(hip[li][dis].abs().max()) <= float((8 * gamma * mag[dis]).max())
+        flips += n
+    # measured: 0-3 per update at B<=512 (~1e7..7e7 units); anything systematic would be thousands
+    assert flips <= max(8, total // 2_000_000), (flips, total)
+    # with its own decisions the oracle's features still agree with the HIP features (a flipped unit is ~0 either way)
+    feat_hip = eng.ws_view("FEAT", B, (2 * B, 39200))[:B]
+    assert nerr(feat_hip, feat) <= 2e-6
+    return flips, total
+
+
+def sync_oracle_state(o, ag):
+    """Copy the HIP agent's complete training state (weights, target, Adam moments and step counts) into an
+    oracle, so that update k>1 is compared from IDENTICAL state instead of through k-1 updates of drift."""
+    dt = o.dtype
+    eng = ag._engine
+    for name, mod, net in (("enc", ag.encoder, "enc"), ("actor", ag.actor, "actor"), ("critic", ag.critic, "critic")):
+        dst = getattr(o, name)
+        for (k, p), off in zip(mod.named_parameters(), eng.layout[net]):
+            n = p.numel()
+            dst[k] = p.detach().cpu().to(dt).clone()
+            o.m[name][k] = eng.adam_m[off:off + n].view(p.shape).cpu().to(dt).clone()
+            o.v[name][k] = eng.adam_v[off:off + n].view(p.shape).cpu().to(dt).clone()
+    for k, p in ag.critic_target.named_parameters():
+        o.critic_target[k] = p.detach().cpu().to(dt).clone()
+    o.t = {"enc": ag.encoder_opt.t, "actor": ag.actor_opt.t, "critic": ag.critic_opt.t}
+
+
 @pytest.fixture(scope="module")
 def golden_steps():
     with gzip.open(os.path.join(G, "steps.json.gz"), "rt") as f:
@@ -70,16 +140,18 @@ def test_update_matches_oracle(name, golden_steps):
     from oracle import drq_oracle as O
     ag = make_agent(cfg)
     o32, o64 = make_oracle(cfg, torch.float32), make_oracle(cfg, torch.float64)
-    base = O.aug_base_grid(84, 4)
     for u in range(cfg["updates"]):
         step = cfg["step0"] + 2 * u
+        if u > 0:
+            # later updates start from the HIP agent's own state (weights, target, Adam moments, step counts):
+            # every update is then held to the first-update tolerances, not to 3e-3 through accumulated drift
+            sync_oracle_state(o32, ag)
+            sync_oracle_state(o64, ag)
         m, batch, (sh_o, sh_n, n_c, n_a) = run_hip(ag, cfg, u)
         # both oracles get the encoder inputs the HIP step produced (aug + /255-0.5; that op is pinned
         # on its own in test_hip_ops): everything downstream then sees identical upstream tensors
         Bq = cfg["B"]
-        xin = ag._engine.ws_view("AUG", Bq, (2 * Bq, cfg["C"], 84, 84)).cpu()
-        ora_in = O.random_shifts_aug(batch[0].float(), sh_o, 4, base) / 255.0 - 0.5
-        assert (xin[:Bq] - ora_in).abs().max().item() <= 1e-6
+        xin = check_encoder_inputs_bitwise(ag, cfg, batch, sh_o, sh_n)     # so injecting them changes nothing
         ov = (xin[:Bq], xin[Bq:])
         # ... and the ReLU decisions of the HIP encoder (obs view): a pre-activation within rounding of zero can
         # fall on either side in two correct fp32 evaluations, and ONE flipped unit at these batch sizes moves the
@@ -92,25 +164,21 @@ def test_update_matches_oracle(name, golden_steps):
         m32 = o32.update(batch, step, sh_o, sh_n, n_c, n_a, **kw)
         m64 = o64.update(batch, step, sh_o, sh_n, n_c, n_a, **kw)
         assert list(m.keys()) == list(m64.keys())
-        # later updates inherit the sign-SGD amplification of Adam at t=1 (SURVEY finding 3)
-        tol = 1e-5 if u == 0 else 3e-3
         for k in m64:
-            assert m[k] == pytest.approx(m64[k], rel=tol, abs=tol), (u, k, m[k], m32[k], m64[k])
-        if u > 0:
-            continue
+            assert m[k] == pytest.approx(m64[k], rel=1e-5, abs=1e-5), (u, k, m[k], m32[k], m64[k])
         B = cfg["B"]
         eng = ag._engine
         # forward: encoder features of both views
         feat = eng.ws_view("FEAT", B, (2 * B, 39200))
         assert nerr(feat[:B], o64.last["feat"]) <= 2e-6
         assert nerr(feat[B:], o64.last["feat_next"]) <= 2e-6
-        # gradients (first update, identical upstream): error vs fp64 no worse than the fp32 oracle's own
+        # gradients (identical upstream state): error vs fp64 no worse than the fp32 oracle's own
         for nm, mod, key in (("enc", ag.encoder, "g_enc"), ("critic", ag.critic, "g_critic"),
                              ("actor", ag.actor, "g_actor")):
             for (pn, p), g64, g32 in zip(mod.named_parameters(), o64.last[key].values(), o32.last[key].values()):
                 e_hip, e_o32 = nerr(p.grad, g64), nerr(g32, g64)
                 lim = max(2.0 * e_o32, 2e-5 if nm != "actor" else 2e-3)
-                assert e_hip <= lim, (nm, pn, e_hip, e_o32)
+                assert e_hip <= lim, (u, nm, pn, e_hip, e_o32)
     # reference's own first-update metrics (real grid_sample aug), fixtures from make_golden.py
     ref = golden_steps[name]["ref_fp32_aug"][0]["metrics"]
     ag2 = make_agent(cfg)
@@ -136,6 +204,12 @@ WIDE = {
     # tiles in its weight gradient
     "humanoid_b128": dict(C=9, A=21, F=100, H=1024, B=128, lr=8e-5, sched="linear(1.0,0.1,2000000)", wseed=8, bseed=80,
                           updates=1, step0=1000, smooth=True),
+    # BASELINE configs[2] at its full shape: quadruped_walk, A=12, batch_size=512
+    "quadruped_b512": dict(C=9, A=12, F=50, H=1024, B=512, lr=1e-4, sched="linear(1.0,0.1,500000)", wseed=9, bseed=90,
+                           updates=1, step0=0, smooth=True),
+    # BASELINE configs[3] at its full single-GPU shape: humanoid_run, A=21, feature_dim=100, batch_size=256
+    "humanoid_b256": dict(C=9, A=21, F=100, H=1024, B=256, lr=8e-5, sched="linear(1.0,0.1,2000000)", wseed=10,
+                          bseed=100, updates=1, step0=1000, smooth=True),
 }
 
 
@@ -148,9 +222,15 @@ def test_wide_batch_update_matches_oracle(name):
     m, batch, (sh_o, sh_n, n_c, n_a) = run_hip(ag, cfg, 0)
     B = cfg["B"]
     eng = ag._engine
-    xin = eng.ws_view("AUG", B, (2 * B, cfg["C"], 84, 84)).cpu()
+    # (a) the encoder inputs the update produced (stacked two-view launch) equal the oracle's aug bit for bit, so
+    # handing them to the oracle below injects nothing the oracle would not have computed itself
+    xin = check_encoder_inputs_bitwise(ag, cfg, batch, sh_o, sh_n)
     ov = (xin[:B], xin[B:])
-    # the ReLU decisions of the HIP encoder (obs view) are handed to the oracles: see oracle.encoder_forward
+    # (b) the oracle's OWN ReLU decisions against the HIP encoder's: counted and bounded, not waived
+    flips, units = check_relu_decisions(ag, cfg, o64, xin[:B])
+    print(f"{name}: {flips} ReLU decisions of {units} differ from the fp64 oracle's (all inside the fp32 error bound)")
+    # (c) gradients are a discontinuous function of those decisions (each flipped unit is an O(1) change on its
+    # path: 1e-3 normwise on the conv gradients), so the gradient comparison hands the HIP decisions to the oracle
     hs = (41, 39, 37, 35)
     acts = [eng.ws_view(nm, B, (2 * B, 32, h, h))[:B].cpu() > 0 for nm, h in zip(("ACT1", "ACT2", "ACT3"), hs)]
     acts.append(eng.ws_view("FEAT", B, (2 * B, 32, 35, 35))[:B].cpu() > 0)
@@ -390,13 +470,18 @@ def test_soak_300_updates_finite_and_reproducible():
     assert m1["critic_loss"] >= 0.0 and abs(m1["critic_q1"]) < 1e3
 
 
-def _dp2_worker(rank, world, port, cfg, ret):
+def _dp2_worker(rank, world, port, cfg, ret, backend="gloo"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)     # gloo moves CUDA tensors through the host:
-    try:                                                              # two ranks can share the one GPU of the box
-        torch.cuda.set_device(0)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":                                             # RCCL: one GPU per rank
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        torch.cuda.set_device(0)                                      # gloo moves CUDA tensors through the host:
+        dist.init_process_group("gloo", rank=rank, world_size=world)  # two ranks can share the one GPU of the box
+    try:
         ag = make_agent(cfg)
         ag.enable_data_parallel(batch_is_global=True, global_metrics=True)
         ref = make_agent(cfg)                                         # same weights, single-process full batch
@@ -419,18 +504,14 @@ def _dp2_worker(rank, world, port, cfg, ret):
         dist.destroy_process_group()
 
 
-def test_two_rank_data_parallel_update_equals_full_batch_on_gpu():
-    """World size 2 on the real kernels: each rank takes half of the same global batch (global shifts/noise sliced),
-    gradients are SUM-all-reduced (gloo carries the CUDA tensors, so both ranks can sit on the box's single GPU)
-    through the overlapped schedule, and the result must equal the one-process full-batch update: gradients to
-    summation-order rounding, metrics to 1e-5."""
+def _run_two_ranks(backend):
     import socket
     import torch.multiprocessing as mp
     cfg = dict(CASES["small_h64_b6"]); cfg["B"] = 8
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_dp2_worker, args=(2, port, cfg, ret), nprocs=2, join=True)
+    mp.spawn(_dp2_worker, args=(2, port, cfg, ret, backend), nprocs=2, join=True)
     assert sorted(ret.keys()) == [0, 1]
     for rank in (0, 1):
         out = ret[rank]
@@ -441,3 +522,18 @@ def test_two_rank_data_parallel_update_equals_full_batch_on_gpu():
             tol = 2e-5 if u == 0 else 5e-3       # update 2 inherits Adam's sign-like first step (SURVEY finding 3)
             assert max(errs.values()) <= tol, (rank, u, errs)
         assert out["cos"] > 0.999
+
+
+def test_two_rank_data_parallel_update_equals_full_batch_on_gpu():
+    """World size 2 on the real kernels: each rank takes half of the same global batch (global shifts/noise sliced),
+    gradients are SUM-all-reduced (gloo carries the CUDA tensors, so both ranks can sit on the box's single GPU)
+    through the overlapped schedule, and the result must equal the one-process full-batch update: gradients to
+    summation-order rounding, metrics to 1e-5."""
+    _run_two_ranks("gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI)")
+def test_two_rank_rccl_update_equals_full_batch():
+    """The same equivalence with one GPU per rank and the gradient exchanges over RCCL (backend nccl): the path
+    bench.py --gpus N takes.  Runs wherever the box shows two or more GPUs."""
+    _run_two_ranks("nccl")
