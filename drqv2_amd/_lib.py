@@ -73,7 +73,7 @@ PROTOTYPES = {
 }
 
 WS_IDS = ["AUG", "ACT1", "ACT2", "ACT3", "FEAT", "Z_NEXT", "Z_OBS", "HA_T", "HA_C", "H_AN", "H_AO", "Q", "TQ",
-          "DQ", "MU_O", "DY4", "DY3", "DY2", "DY1", "DZ_C", "DZ_A", "HA_C2"]
+          "DQ", "MU_O", "DY4", "DY3", "DY2", "DY1", "DZ_C", "DZ_A", "HA_C2", "P1", "P2", "C1", "C2"]
 
 _lib = None
 

@@ -125,10 +125,11 @@ enum {
   W_H_AN = DRQ_WS_H_AN, W_H_AO = DRQ_WS_H_AO, W_Q = DRQ_WS_Q, W_TQ = DRQ_WS_TQ, W_DQ = DRQ_WS_DQ,
   W_MU_O = DRQ_WS_MU_O, W_DY4 = DRQ_WS_DY4, W_DY3 = DRQ_WS_DY3, W_DY2 = DRQ_WS_DY2, W_DY1 = DRQ_WS_DY1,
   W_DZ_C = DRQ_WS_DZ_C, W_DZ_A = DRQ_WS_DZ_A, W_HA_C2 = DRQ_WS_HA_C2,
+  W_P1 = DRQ_WS_P1, W_P2 = DRQ_WS_P2,             // policy activations over 2B rows (obs, next)
+  W_C1 = DRQ_WS_C1, W_C2 = DRQ_WS_C2,             // critic-Q hidden activations
   W_XHAT_C = DRQ_WS_NBUF_PUBLIC, W_RSTD_C, W_XHAT_A, W_RSTD_A, W_Z_C2,
-  W_HROWS, W_P1, W_P2, W_P3, W_Z4,                // actor trunk output / policy activations over 2B rows (obs, next)
+  W_HROWS, W_P3, W_Z4,                            // actor trunk output / policy output over 2B rows
   W_T1, W_T2,                                     // target-Q hidden activations, reused by the actor step
-  W_C1, W_C2,                                     // critic-Q hidden activations
   W_DC2, W_DC1, W_DHA, W_DLN, W_DPRE, W_DP2, W_DP1, W_DH_A, W_DA,
   W_GEMM_WS, W_CONV_WS, W_COUNT
 };

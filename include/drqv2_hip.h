@@ -196,7 +196,10 @@ long drq_step_ws_offset(int B, int C, int A, int F, int H, int buffer_id);
 enum {
   DRQ_WS_AUG = 0, DRQ_WS_ACT1, DRQ_WS_ACT2, DRQ_WS_ACT3, DRQ_WS_FEAT, DRQ_WS_Z_NEXT, DRQ_WS_Z_OBS,
   DRQ_WS_HA_T, DRQ_WS_HA_C, DRQ_WS_H_AN, DRQ_WS_H_AO, DRQ_WS_Q, DRQ_WS_TQ, DRQ_WS_DQ, DRQ_WS_MU_O,
-  DRQ_WS_DY4, DRQ_WS_DY3, DRQ_WS_DY2, DRQ_WS_DY1, DRQ_WS_DZ_C, DRQ_WS_DZ_A, DRQ_WS_HA_C2, DRQ_WS_NBUF_PUBLIC
+  DRQ_WS_DY4, DRQ_WS_DY3, DRQ_WS_DY2, DRQ_WS_DY1, DRQ_WS_DZ_C, DRQ_WS_DZ_A, DRQ_WS_HA_C2,
+  DRQ_WS_P1, DRQ_WS_P2,   /* policy hidden activations (post-ReLU), [2B][H]: rows [0,B) obs, [B,2B) next_obs */
+  DRQ_WS_C1, DRQ_WS_C2,   /* critic Q hidden activations (post-ReLU) of the critic loss, [2 heads][B][H] */
+  DRQ_WS_NBUF_PUBLIC
 };
 
 /* One update = phases 3..9 in this order (phase -1 runs them all: single GPU):

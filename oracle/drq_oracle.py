@@ -164,20 +164,31 @@ def trunk_forward(p, feat):
     return torch.tanh(layer_norm(z, p["trunk.1.weight"], p["trunk.1.bias"]))
 
 
-def mlp3(p, prefix, x):
-    x = torch.relu(x @ p[f"{prefix}.0.weight"].t() + p[f"{prefix}.0.bias"])
-    x = torch.relu(x @ p[f"{prefix}.2.weight"].t() + p[f"{prefix}.2.bias"])
-    return x @ p[f"{prefix}.4.weight"].t() + p[f"{prefix}.4.bias"]
+def mlp3(p, prefix, x, masks=None, rec=None):
+    """masks (tests only): two boolean tensors replacing the ReLU decisions of the two hidden layers (same reason as
+    encoder_forward's relu_masks).  rec (tests only): a list that receives, per hidden layer, (pre-activation, layer
+    input) of THIS evaluation -- the pre-activations are the function's own, before any injected decision."""
+    z1 = x @ p[f"{prefix}.0.weight"].t() + p[f"{prefix}.0.bias"]
+    h1 = torch.relu(z1) if masks is None else z1 * masks[0].to(z1.dtype)
+    z2 = h1 @ p[f"{prefix}.2.weight"].t() + p[f"{prefix}.2.bias"]
+    h2 = torch.relu(z2) if masks is None else z2 * masks[1].to(z2.dtype)
+    if rec is not None:
+        rec.append((z1.detach(), x.detach()))
+        rec.append((z2.detach(), h1.detach()))
+    return h2 @ p[f"{prefix}.4.weight"].t() + p[f"{prefix}.4.bias"]
 
 
 def actor_mu(p, feat):
     return torch.tanh(mlp3(p, "policy", trunk_forward(p, feat)))  # drqv2.py:86-89
 
 
-def critic_q(p, feat, action):
+def critic_q(p, feat, action, masks=None, rec=None):
+    """masks / rec (tests only): {"Q1": (m1, m2), "Q2": (m1, m2)} / {"Q1": [], "Q2": []}, see mlp3."""
     h = trunk_forward(p, feat)
     ha = torch.cat([h, action], dim=-1)                           # drqv2.py:117
-    return mlp3(p, "Q1", ha), mlp3(p, "Q2", ha)
+    mk = lambda q: None if masks is None else masks[q]
+    rc = lambda q: None if rec is None else rec[q]
+    return mlp3(p, "Q1", ha, mk("Q1"), rc("Q1")), mlp3(p, "Q2", ha, mk("Q2"), rc("Q2"))
 
 
 def trunc_normal_sample(mu, noise, std, clip):
@@ -317,7 +328,8 @@ class OracleAgent:
 
     # -- the hot path ----------------------------------------------------
     def update(self, batch, step, shifts_obs, shifts_next, noise_critic, noise_actor,
-               aug_base=None, aug_override=None, enc_in_override=None, keep=False, relu_masks=None):
+               aug_base=None, aug_override=None, enc_in_override=None, keep=False, relu_masks=None,
+               critic_relu_masks=None):
         """batch = (obs u8 [B,C,84,84], action [B,A], reward [B,1], discount [B,1],
         next_obs u8).  Returns the 8-key metrics dict of drqv2.py (python floats)."""
         if step % self.update_every_steps != 0:
@@ -355,7 +367,8 @@ class OracleAgent:
             a_next = trunc_normal_sample(mu_n, noise_critic, std, clip)
             tq1, tq2 = critic_q(self.critic_target, feat_next, a_next)
             target_q = reward + discount * torch.minimum(tq1, tq2)
-        q1, q2 = critic_q(critic, feat, action)
+        crit_rec = {"Q1": [], "Q2": []} if keep else None
+        q1, q2 = critic_q(critic, feat, action, critic_relu_masks, crit_rec)
         critic_loss = ((q1 - target_q) ** 2).mean() + ((q2 - target_q) ** 2).mean()
         metrics["critic_target_q"] = target_q.mean().item()
         metrics["critic_q1"] = q1.mean().item()
@@ -392,7 +405,8 @@ class OracleAgent:
                              acts=[t.detach() for t in acts], mu_next=mu_n, a_next=a_next,
                              target_q=target_q, q1=q1.detach(), q2=q2.detach(),
                              g_enc=g_enc, g_critic=g_critic, g_actor=g_actor,
-                             mu=mu.detach(), a=a.detach(), aq1=aq1.detach(), aq2=aq2.detach())
+                             mu=mu.detach(), a=a.detach(), aq1=aq1.detach(), aq2=aq2.detach(),
+                             critic_pre=crit_rec)
         return metrics
 
 

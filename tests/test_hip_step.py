@@ -111,6 +111,41 @@ def check_relu_decisions(ag, cfg, o64, xin_obs):
     return flips, total
 
 
+def hip_masks(ag, cfg):
+    """The ReLU decisions the HIP update took: the four encoder layers (obs view) and the two hidden layers of both
+    Q heads in the critic loss.  Handed to the oracle for the GRADIENT comparison only (gradients are a discontinuous
+    function of these decisions: one flipped unit among millions moves a whole gradient tensor by 1e-4..1e-3
+    normwise); check_relu_decisions / check_critic_decisions bound how many differ from the oracle's own."""
+    B, H = cfg["B"], cfg["H"]
+    eng = ag._engine
+    enc = [eng.ws_view(nm, B, (2 * B, 32, h, h))[:B].cpu() > 0 for nm, h in zip(("ACT1", "ACT2", "ACT3"), (41, 39, 37))]
+    enc.append(eng.ws_view("FEAT", B, (2 * B, 32, 35, 35))[:B].cpu() > 0)
+    c1 = eng.ws_view("C1", B, (2, B, H)).cpu() > 0
+    c2 = eng.ws_view("C2", B, (2, B, H)).cpu() > 0
+    return enc, {"Q1": (c1[0], c2[0]), "Q2": (c1[1], c2[1])}
+
+
+def check_critic_decisions(o64, critic_before, crit_masks):
+    """ReLU decisions of the critic's hidden layers (critic loss forward): the fp64 oracle's own pre-activations
+    (o64.last["critic_pre"], recorded before any injected decision is applied) against the HIP decisions.  A
+    disagreement must sit inside the fp32 forward-error bound of its dot product; their number is bounded."""
+    flips = total = 0
+    for q in ("Q1", "Q2"):
+        for li, (z, x) in enumerate(o64.last["critic_pre"][q]):
+            w, b = critic_before[f"{q}.{2 * li}.weight"], critic_before[f"{q}.{2 * li}.bias"]
+            dis = (z > 0) != crit_masks[q][li]
+            n = int(dis.sum())
+            total += z.numel()
+            if n:
+                mag = x.abs() @ w.abs().t() + b.abs()
+                gamma = (w.shape[1] + 1) * 2.0 ** -24
+                worst = float((z.abs()[dis] / (4 * gamma * mag[dis])).max())
+                assert worst <= 1.0, (q, li, n, worst)
+            flips += n
+    assert flips <= max(4, total // 250_000), (flips, total)
+    return flips, total
+
+
 def sync_oracle_state(o, ag):
     """Copy the HIP agent's complete training state (weights, target, Adam moments and step counts) into an
     oracle, so that update k>1 is compared from IDENTICAL state instead of through k-1 updates of drift."""
@@ -153,16 +188,16 @@ def test_update_matches_oracle(name, golden_steps):
         Bq = cfg["B"]
         xin = check_encoder_inputs_bitwise(ag, cfg, batch, sh_o, sh_n)     # so injecting them changes nothing
         ov = (xin[:Bq], xin[Bq:])
-        # ... and the ReLU decisions of the HIP encoder (obs view): a pre-activation within rounding of zero can
-        # fall on either side in two correct fp32 evaluations, and ONE flipped unit at these batch sizes moves the
-        # first conv layer's gradient by ~5e-4 (see oracle.encoder_forward)
-        eng_ = ag._engine
-        acts = [eng_.ws_view(nm, Bq, (2 * Bq, 32, h, h))[:Bq].cpu() > 0
-                for nm, h in zip(("ACT1", "ACT2", "ACT3"), (41, 39, 37))]
-        acts.append(eng_.ws_view("FEAT", Bq, (2 * Bq, 32, 35, 35))[:Bq].cpu() > 0)
-        kw = dict(enc_in_override=ov, keep=True, relu_masks=acts)
+        # ... and the ReLU decisions of the HIP step (encoder, critic hidden layers): a pre-activation within
+        # rounding of zero can fall on either side in two correct fp32 evaluations, and ONE flipped unit at these
+        # batch sizes moves the first conv layer's gradient by ~5e-4 (see oracle.encoder_forward)
+        check_relu_decisions(ag, cfg, o64, xin[:Bq])
+        acts, crit_masks = hip_masks(ag, cfg)
+        critic_before = {k: v.clone() for k, v in o64.critic.items()}
+        kw = dict(enc_in_override=ov, keep=True, relu_masks=acts, critic_relu_masks=crit_masks)
         m32 = o32.update(batch, step, sh_o, sh_n, n_c, n_a, **kw)
         m64 = o64.update(batch, step, sh_o, sh_n, n_c, n_a, **kw)
+        check_critic_decisions(o64, critic_before, crit_masks)
         assert list(m.keys()) == list(m64.keys())
         for k in m64:
             assert m[k] == pytest.approx(m64[k], rel=1e-5, abs=1e-5), (u, k, m[k], m32[k], m64[k])
@@ -231,12 +266,13 @@ def test_wide_batch_update_matches_oracle(name):
     print(f"{name}: {flips} ReLU decisions of {units} differ from the fp64 oracle's (all inside the fp32 error bound)")
     # (c) gradients are a discontinuous function of those decisions (each flipped unit is an O(1) change on its
     # path: 1e-3 normwise on the conv gradients), so the gradient comparison hands the HIP decisions to the oracle
-    hs = (41, 39, 37, 35)
-    acts = [eng.ws_view(nm, B, (2 * B, 32, h, h))[:B].cpu() > 0 for nm, h in zip(("ACT1", "ACT2", "ACT3"), hs)]
-    acts.append(eng.ws_view("FEAT", B, (2 * B, 32, 35, 35))[:B].cpu() > 0)
-    kw = dict(enc_in_override=ov, keep=True, relu_masks=acts)
+    acts, crit_masks = hip_masks(ag, cfg)
+    critic_before = {k: v.clone() for k, v in o64.critic.items()}
+    kw = dict(enc_in_override=ov, keep=True, relu_masks=acts, critic_relu_masks=crit_masks)
     m32 = o32.update(batch, cfg["step0"], sh_o, sh_n, n_c, n_a, **kw)
     m64 = o64.update(batch, cfg["step0"], sh_o, sh_n, n_c, n_a, **kw)
+    cflips, cunits = check_critic_decisions(o64, critic_before, crit_masks)
+    print(f"{name}: {cflips} of {cunits} critic hidden-layer decisions differ (inside the fp32 error bound)")
     for k in m64:
         assert m[k] == pytest.approx(m64[k], rel=1e-5, abs=1e-5), (k, m[k], m32[k], m64[k])
     feat = eng.ws_view("FEAT", B, (2 * B, 39200))
