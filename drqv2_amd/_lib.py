@@ -28,6 +28,7 @@ class DrqStep(C.Structure):
         ("gscale", C.c_float),
         ("stream", stream_t),
         ("sums_host", c_float_p),
+        ("store_aug_next", C.c_int),
         ("timing_events", C.POINTER(C.c_void_p)),
     ]
 
@@ -39,6 +40,7 @@ PROTOTYPES = {
     "drq_abi_version": (I, []),
     "drq_aug_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
     "drq_aug_fwd_f32": (I, [P, P, P, P, I, I, I, I, P]),
+    "drq_conv1_aug_fwd": (I, [P, P, P, P, P, P, P, P, P, I, I, P]),
     "drq_conv3x3_fwd": (I, [P, P, P, P, I, I, I, I, I, L, L, L, L, P]),
     "drq_conv3x3_dgrad": (I, [P, P, P, P, I, I, L, L, L, L, P]),
     "drq_conv3x3_wgrad": (I, [P, P, P, P, I, I, I, I, L, L, L, L, P, SZ, P]),
@@ -100,7 +102,7 @@ def load(dev=False):
         fn = getattr(lib, name)       # AttributeError = ABI mismatch, also loud
         fn.restype = res
         fn.argtypes = args
-    if lib.drq_abi_version() != 3:
+    if lib.drq_abi_version() != 4:
         raise DrqError("libdrqv2_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -1061,22 +1061,6 @@ DRQ_API int drq_aug_fwd(const uint8_t* obs, const float* shift_xy, const float* 
   return DRQ_OK;
 }
 
-// internal (step.hip): both views of the update in one launch; out = [2n][c][hw][hw], obs rows first
-int drq_aug_fwd_pair(const uint8_t* obs, const float* shift, const uint8_t* obs1, const float* shift1,
-                     const float* base_grid, float* out, int n, int c, int hw, int pad, int fuse_norm, hipStream_t st) {
-  if (!obs || !shift || !obs1 || !shift1 || !base_grid || !out || n <= 0 || c <= 0 || hw <= 0 || pad < 0)
-    return DRQ_EARG;
-  if (launch_aug_rows(obs, shift, obs1, shift1, base_grid, out, n, c, hw, pad, fuse_norm, st)) {
-    DRQ_LAUNCH_CHECK();
-    return DRQ_OK;
-  }
-  const long total = (long)n * hw * hw;
-  hipLaunchKernelGGL(aug_kernel<uint8_t>, dim3((unsigned)((total + 255) / 256), 2), dim3(256), 0, st, obs, shift,
-                     base_grid, out, n, c, hw, pad, fuse_norm, obs1, shift1);
-  DRQ_LAUNCH_CHECK();
-  return DRQ_OK;
-}
-
 // same op on a float frame (RandomShiftsAug.forward is handed obs.float(), drqv2.py:241)
 DRQ_API int drq_aug_fwd_f32(const float* x, const float* shift_xy, const float* base_grid, float* out, int n, int c, int hw,
                     int pad, hipStream_t st) {

@@ -11,9 +11,6 @@ extern "C" int drq_ln_tanh_fwd_multi_part(int n, const float* const* z, int ldz,
                                           const float* const* tail, const int* tail_ld, int tail_n, const float* part,
                                           const float* const* bias, int splitk, hipStream_t st);
 // elementwise.hip (internal)
-extern "C" int drq_aug_fwd_pair(const uint8_t* obs, const float* shift, const uint8_t* obs1, const float* shift1,
-                                const float* base_grid, float* out, int n, int c, int hw, int pad, int fuse_norm,
-                                hipStream_t st);
 extern "C" int drq_qout_bwd_td(const float* tq1, const float* tq2, const float* q1, const float* q2, const float* reward,
                                const float* discount, float inv_global_B, float* sums, const float* const* h,
                                const float* const* w, float* const* dh, float* const* dw, float* const* db, int B,
@@ -232,13 +229,14 @@ struct Ctx {
   }
 };
 
+// x == nullptr: a1 already holds the first layer's output (fused aug + conv1), start at layer 2
 int encoder_forward(const Ctx& c, const float* x, int nb, float* a1, float* a2, float* a3, float* a4,
                     bool timed = false) {
   const ParamLayout& P = c.P;
   float* outs[4] = {a1, a2, a3, a4};
-  const float* in = x;
+  const float* in = x ? x : a1;
   void* const* ev = timed ? c.s->timing_events : nullptr;
-  for (int l = 0; l < 4; ++l) {
+  for (int l = x ? 0 : 1; l < 4; ++l) {
     const int hin = kEncH[l], hout = kEncH[l + 1];
     if (ev && l == 1 && hipEventRecord((hipEvent_t)ev[0], c.st) != hipSuccess) return DRQ_EARG;
     CK(drq_conv3x3_fwd(in, c.p(P.enc_w[l]), c.p(P.enc_b[l]), outs[l], nb, l == 0 ? c.s->C : 32, hin, l == 0 ? 2 : 1,
@@ -314,10 +312,13 @@ int phase_encode(const Ctx& c) {
   const int B = s->B, C = s->C;
   hipStream_t st = c.st;
   float* aug = c.ws(W_AUG);
-  // aug (drqv2.py:241-242) + /255-0.5 (:64); rows [0,B) = obs, [B,2B) = next_obs
-  CK(drq_aug_fwd_pair(s->obs, s->shift_obs, s->next_obs, s->shift_next, s->base_grid, aug, B, C, 84, 4, 1, st));
-  // encoder on both views in one pass (:244-246)
-  CK(encoder_forward(c, aug, 2 * B, c.ws(W_ACT1), c.ws(W_ACT2), c.ws(W_ACT3), c.ws(W_FEAT), true));
+  // aug (drqv2.py:241-242) + /255-0.5 (:64) + conv1 (:55) in one kernel that reads the uint8 frames once; rows
+  // [0,B) = obs, [B,2B) = next_obs.  Only the obs view's encoder input is kept (conv1's weight gradient reads it).
+  (void)C;
+  CK(drq_conv1_aug_fwd(s->obs, s->shift_obs, s->next_obs, s->shift_next, s->base_grid, c.p(c.P.enc_w[0]),
+                       c.p(c.P.enc_b[0]), aug, c.ws(W_ACT1), B, s->store_aug_next ? 2 * B : B, st));
+  // layers 2..4 on both views in one pass (:244-246)
+  CK(encoder_forward(c, nullptr, 2 * B, c.ws(W_ACT1), c.ws(W_ACT2), c.ws(W_ACT3), c.ws(W_FEAT), true));
   return 0;
 }
 
@@ -624,7 +625,7 @@ int check_step(const DrqStep* s) {
 
 extern "C" {
 
-DRQ_API int drq_abi_version(void) { return 3; }
+DRQ_API int drq_abi_version(void) { return 4; }
 
 DRQ_API int drq_param_layout(int C, int A, int F, int H, long* out, int cap) {
   if (!out || cap < DRQ_PARAM_LAYOUT_LEN || C <= 0 || A <= 0 || F <= 0 || H <= 0) return DRQ_EARG;

@@ -240,6 +240,7 @@ class StepEngine:
         self._timing_array = None # ctypes array of 4 hipEvent_t (set_timing_events)
         self._side = None         # side stream of the metric-sums exchange
         self._side_busy = False
+        self.store_aug_next = False   # verification: keep the next_obs view's encoder input too (DrqStep.store_aug_next)
         self.world = 1
         self.rank = 0
         self.exchange = None      # GradExchange (enable_data_parallel)
@@ -375,6 +376,7 @@ class StepEngine:
         d.gscale = 1.0
         d.stream = self._stream()
         d.sums_host = ptr(self.sums_host) if (self.pg is None and self.sums_host is not None) else None
+        d.store_aug_next = int(self.store_aug_next)
         d.timing_events = self._timing_array      # None, or 4 hipEvent_t for bench.py's roofline
         return d
 

@@ -52,6 +52,25 @@ def random_shifts_aug(x, shift, pad=4, base=None, fuse_norm=False):
     return out
 
 
+def conv1_aug_fwd(obs, shift, obs1, shift1, w, b, n_store=None, base=None):
+    """Fused RandomShiftsAug + /255-0.5 + conv1 + ReLU on both views (drq_conv1_aug_fwd).
+    Returns (y [2n,32,41,41], xaug [2n,9,84,84] with frames [0,n_store) written, the rest zero)."""
+    lib = _lib.load()
+    n = obs.shape[0]
+    _need(obs, torch.uint8, "obs")
+    _need(obs1, torch.uint8, "obs1")
+    if tuple(obs.shape[1:]) != (9, 84, 84) or obs1.shape != obs.shape:
+        raise _lib.DrqError("conv1_aug_fwd: frames must be [n,9,84,84]")
+    shift, shift1 = _need(shift.reshape(n, 2), name="shift"), _need(shift1.reshape(n, 2), name="shift1")
+    base = aug_base_grid(84, 4, obs.device) if base is None else _need(base, name="base")
+    n_store = n if n_store is None else n_store
+    y = torch.empty((2 * n, 32, 41, 41), device=obs.device, dtype=torch.float32)
+    xaug = torch.zeros((2 * n, 9, 84, 84), device=obs.device, dtype=torch.float32)
+    check(lib.drq_conv1_aug_fwd(ptr(obs), ptr(shift), ptr(obs1), ptr(shift1), ptr(base), ptr(_need(w, name="w")),
+                                ptr(_need(b, name="b")), ptr(xaug), ptr(y), n, n_store, _stream()), "drq_conv1_aug_fwd")
+    return y, xaug
+
+
 def u8_normalize(x):
     lib = _lib.load()
     _need(x, torch.uint8, "obs")

@@ -39,6 +39,17 @@ int drq_aug_fwd(const uint8_t* obs, const float* shift_xy, const float* base_gri
 int drq_aug_fwd_f32(const float* x, const float* shift_xy, const float* base_grid, float* out, int n, int c,
                     int hw, int pad, drq_stream_t stream);
 
+/* ---- RandomShiftsAug of BOTH views (drqv2.py:241-242) + obs/255-0.5 (:64) + the first encoder layer
+ * Conv2d(9,32,3,stride 2)+ReLU (:55) in one launch that reads the uint8 frames once (frame_stack 3, 84x84, pad 4).
+ * obs / obs1 u8 [n][9][84][84] (4-byte aligned), shift / shift1 f32 [n][2], base_grid f32 [84], w [32][9][3][3],
+ * bias [32].  y f32 [2n][32][41][41]: frames [0,n) = obs view, [n,2n) = obs1 view.  xaug f32 [2n][9][84][84]:
+ * the augmented, normalised encoder input of frames [0, n_store) is also written there (the update stores the
+ * obs view, n_store = n, for conv1's weight gradient; tests store both views; 0 = none, xaug may be NULL).
+ * Values are bit-identical to drq_aug_fwd(fuse_norm=1) followed by drq_conv3x3_fwd. */
+int drq_conv1_aug_fwd(const uint8_t* obs, const float* shift, const uint8_t* obs1, const float* shift1,
+                      const float* base_grid, const float* w, const float* bias, float* xaug, float* y, int n,
+                      int n_store, drq_stream_t stream);
+
 /* ---- Encoder conv layers (drqv2.py:55-59): Conv2d(cin,32,3,stride)+ReLU, 32 output channels.
  * Supported (cin,hin,stride): (9,84,2) (32,41,1) (32,39,1) (32,37,1).  y element (b,co,oy,ox) is
  * written at y[y_off + b*y_bs + co*y_cs + oy*y_rs + ox]. */
@@ -176,6 +187,9 @@ typedef struct {
                               * reads the metrics (drqv2.py:191-198,218-223: the .item() calls) by polling slot 8
                               * instead of draining the stream.  Single-GPU only: with data parallelism the sums
                               * are partial until the host has all-reduced them. */
+  int store_aug_next;        /* 0: only the obs view's augmented encoder input is kept in the AUG workspace buffer (rows
+                              * [0,B); conv1's weight gradient reads it).  1 (verification): the next_obs view is
+                              * stored as well (rows [B,2B)), 65 MB more traffic at B=256. */
   void* const* timing_events; /* optional (may be NULL): host array of 4 hipEvent_t created with timing enabled.
                               * Instrumentation for bench.py's roofline: [0],[1] are recorded on `stream` right
                               * before / after the conv2 forward launch of phase 3, [2],[3] around the conv3 dgrad

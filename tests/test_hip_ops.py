@@ -230,6 +230,29 @@ def test_gemm_batched_wgrad_with_fused_bias_grad(ops, Brows, N, K, n):
         assert nerr(r, dy.double().sum(0)) <= 3e-6
 
 
+@pytest.mark.parametrize("n", [1, 3, 32, 200])
+def test_fused_aug_conv1_is_bit_identical_to_the_two_kernel_path(ops, n):
+    """drq_conv1_aug_fwd (what the update runs) against drq_aug_fwd(fuse_norm) + drq_conv3x3_fwd: same encoder
+    input (also equal to the oracle's aug bit for bit, test_aug_vs_oracle_and_reference) and same layer output, both
+    views, every one of the 81 shifts present; frames >= n_store are not written."""
+    g = torch.Generator().manual_seed(n)
+    obs = torch.randint(0, 256, (n, 9, 84, 84), generator=g, dtype=torch.uint8).cuda()
+    obs1 = torch.randint(0, 256, (n, 9, 84, 84), generator=g, dtype=torch.uint8).cuda()
+    sh = torch.randint(0, 9, (n, 2), generator=g).float()
+    sh1 = torch.randint(0, 9, (n, 2), generator=g).float()
+    if n >= 81:
+        sh[:81] = torch.tensor([[a, b] for a in range(9) for b in range(9)], dtype=torch.float32)
+    sh, sh1 = sh.cuda(), sh1.cuda()
+    w, b = (rnd(32, 9, 3, 3, seed=5) * 0.2).cuda(), (rnd(32, seed=6) * 0.1).cuda()
+    y, xaug = ops.conv1_aug_fwd(obs, sh, obs1, sh1, w, b, n_store=2 * n)
+    x0 = ops.random_shifts_aug(obs, sh, 4, fuse_norm=True)
+    x1 = ops.random_shifts_aug(obs1, sh1, 4, fuse_norm=True)
+    assert torch.equal(xaug[:n], x0) and torch.equal(xaug[n:], x1)
+    assert torch.equal(y[:n], ops.conv3x3_fwd(x0, w, b, 2)) and torch.equal(y[n:], ops.conv3x3_fwd(x1, w, b, 2))
+    y2, xaug2 = ops.conv1_aug_fwd(obs, sh, obs1, sh1, w, b)            # the update's form: obs view stored only
+    assert torch.equal(y2, y) and torch.equal(xaug2[:n], x0) and not bool(xaug2[n:].any())
+
+
 @pytest.mark.parametrize("cin,hin,stride,nb", [(9, 84, 2, 256), (32, 41, 1, 512), (32, 39, 1, 256), (32, 37, 1, 96)])
 def test_conv_kernels_at_training_batch_sizes(ops, cin, hin, stride, nb):
     """Forward, dgrad and wgrad at the batch sizes of the training step, where a wave walks several pixel tiles
