@@ -138,6 +138,10 @@ class DrQV2Agent:
 
         self.aug = RandomShiftsAug(pad=4)
         self._draw_hook = None     # tests inject the four random draws here
+        # False: update() returns python floats like the reference (its .item() calls, drqv2.py:191-198,223-226).
+        # True: it returns 0-d DEVICE tensors and never waits for the GPU; Logger.log() calls .item() on tensors
+        # itself (logger.py:143-144), so train.py works unchanged and the wait moves to the logging cadence.
+        self.metrics_on_device = False
 
         self.train()
         self.critic_target.train()
@@ -210,7 +214,17 @@ class DrQV2Agent:
                           next_l.contiguous(), f32(sh_o), f32(sh_n), f32(n_c), f32(n_a), stddev, self.stddev_clip,
                           self.critic_target_tau, B_global=n_global)
 
-        if self.use_tb:
+        if self.use_tb and self.metrics_on_device:
+            inv = 1.0 / (n_global if (eng.pg is None or eng.global_metrics) else (hi - lo))
+            if eng._side_busy:           # data parallel with global metrics: the sums exchange runs on a side stream
+                torch.cuda.current_stream(eng.device).wait_stream(eng._side)
+            vals = sums[:7] * inv        # a fresh tensor: the sums buffer is overwritten by the next update
+            for i, k in enumerate(("batch_reward", "critic_target_q", "critic_q1", "critic_q2", "critic_loss",
+                                   "actor_loss", "actor_logprob")):
+                metrics[k] = vals[i]
+            metrics["actor_ent"] = torch.tensor(A * (0.5 + 0.5 * math.log(2 * math.pi) + math.log(stddev)),
+                                                dtype=torch.float32)
+        elif self.use_tb:
             s = eng.read_sums()          # the single device->host wait of the update
             # data parallel without global_metrics: the sums cover this rank's rows only
             inv = 1.0 / (n_global if (eng.pg is None or eng.global_metrics) else (hi - lo))
@@ -230,6 +244,58 @@ class DrQV2Agent:
         all-reduce.  update(), act() and snapshots do this themselves; call it before reading actor weights
         directly."""
         self._engine.flush()
+
+    # ---- weights-only interchange with the reference's classes (SURVEY 8f rank 3) -----------------------------
+    def export_reference_state(self):
+        """The agent as plain tensors in the formats the REFERENCE's objects load with their own methods:
+        `state_dict()`s of the four nn.Modules (same keys: drqv2.py:48-121) and `torch.optim.Adam.state_dict()`s of the
+        three optimisers (drqv2.py:148-150: per-parameter `step`, `exp_avg`, `exp_avg_sq`, one param group).
+        No code is pickled: `torch.save(agent.export_reference_state(), f)` loads with `weights_only=True`, and a
+        reference agent takes it with `agent.encoder.load_state_dict(s["encoder"])` ...
+        `agent.encoder_opt.load_state_dict(s["encoder_opt"])`."""
+        self._engine.flush()
+        cpu = lambda sd: {k: v.detach().cpu().clone() for k, v in sd.items()}
+        out = {"format": "drqv2-reference-state-v1",
+               "encoder": cpu(self.encoder.state_dict()), "actor": cpu(self.actor.state_dict()),
+               "critic": cpu(self.critic.state_dict()), "critic_target": cpu(self.critic_target.state_dict())}
+        eng = self._engine
+        for net, opt_name, mod in (("enc", "encoder_opt", self.encoder), ("actor", "actor_opt", self.actor),
+                                   ("critic", "critic_opt", self.critic)):
+            opt = getattr(self, opt_name)
+            state = {}
+            plist = list(mod.parameters())
+            if opt.t > 0:
+                for i, (p, off) in enumerate(zip(plist, eng.layout[net])):
+                    n = p.numel()
+                    state[i] = {"step": torch.tensor(float(opt.t)),
+                                "exp_avg": eng.adam_m[off:off + n].view(p.shape).detach().cpu().clone(),
+                                "exp_avg_sq": eng.adam_v[off:off + n].view(p.shape).detach().cpu().clone()}
+            group = dict(lr=opt.lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, maximize=False,
+                         foreach=None, capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False,
+                         params=list(range(len(plist))))
+            out[opt_name] = {"state": state, "param_groups": [group]}
+        return out
+
+    def import_reference_state(self, st):
+        """The reverse: weights, target and Adam state from `export_reference_state()`-shaped data, e.g. what a
+        reference agent produces with {name: module.state_dict()} and {name: optimiser.state_dict()}."""
+        for n in ("encoder", "actor", "critic", "critic_target"):
+            getattr(self, n).load_state_dict(st[n])
+        eng = self._engine
+        for net, opt_name in (("enc", "encoder_opt"), ("actor", "actor_opt"), ("critic", "critic_opt")):
+            mine = getattr(self, opt_name)
+            ref = st[opt_name]["state"]
+            t = 0
+            for i, off in enumerate(eng.layout[net]):
+                ent = ref.get(i, ref.get(str(i)))
+                if ent is None:
+                    continue
+                m, v = ent["exp_avg"], ent["exp_avg_sq"]
+                eng.adam_m[off:off + m.numel()].copy_(m.reshape(-1))
+                eng.adam_v[off:off + v.numel()].copy_(v.reshape(-1))
+                t = max(t, int(ent["step"]))
+            mine.t = t
+            mine.param_groups[0]["lr"] = st[opt_name]["param_groups"][0]["lr"]
 
     def __getstate__(self):
         self._engine.flush()

@@ -6,9 +6,18 @@ The reference writes every finished episode to an .npz file which DataLoader wor
 sampled batch host -> device.  Here a finished episode goes straight into a device-resident store
 (`drqv2_amd.replay.DeviceReplay`) and the loader's iterator assembles batches on the GPU with one HIP launch
 (`drq_nstep_gather`): what `DrQV2Agent.update` receives has the same shapes, dtypes and n-step arithmetic
-(`replay_buffer.py:142-160`), already in HBM.  `num_workers` and `save_snapshot` are accepted and unused: there are
-no worker processes and nothing is written to disk.
+(`replay_buffer.py:142-160`), already in HBM.  `num_workers` is accepted and unused (no worker processes).
+
+Resume (train.py:192-204 + `save_snapshot: true`): the reference keeps every episode as
+`<replay_dir>/<timestamp>_<idx>_<len>.npz` when save_snapshot is set (its workers delete the files otherwise,
+replay_buffer.py:114-115) and reloads them after a restart (`_preload`, `_try_fetch`).  The same here: with
+save_snapshot the storage writes the reference's files, and `make_replay_loader` loads the newest episodes found in
+`replay_dir` (up to `max_size` transitions, oldest first) into the device store, so `agent.update()` has data right
+after `load_snapshot()` -- the reference's own files load too.
 """
+import datetime
+import io
+import pathlib
 from collections import defaultdict
 
 import numpy as np
@@ -16,7 +25,7 @@ import torch
 
 from drqv2_amd.replay import DeviceReplay
 
-_REGISTRY = {}      # str(replay_dir) -> {"store": DeviceReplay | None, "pending": [episodes], "specs": data_specs}
+_REGISTRY = {}      # str(replay_dir) -> {"store", "pending": [episodes], "specs", "save_snapshot"}
 
 
 def episode_len(episode):
@@ -25,7 +34,35 @@ def episode_len(episode):
 
 
 def _entry(replay_dir):
-    return _REGISTRY.setdefault(str(replay_dir), {"store": None, "pending": [], "specs": None})
+    return _REGISTRY.setdefault(str(replay_dir), {"store": None, "pending": [], "specs": None, "save_snapshot": False})
+
+
+def save_episode(episode, fn):
+    """replay_buffer.py:22-27: one compressed npz per episode"""
+    with io.BytesIO() as bs:
+        np.savez_compressed(bs, **episode)
+        bs.seek(0)
+        with open(fn, "wb") as f:
+            f.write(bs.read())
+
+
+def load_episode(fn):
+    """replay_buffer.py:30-34 (np.load default: no pickles)"""
+    with open(fn, "rb") as f:
+        ep = np.load(f)
+        return {k: ep[k] for k in ep.keys()}
+
+
+def _episode_files(replay_dir):
+    """[(path, idx, len)] of the reference-named files in replay_dir, oldest first (names sort by time stamp)"""
+    d = pathlib.Path(replay_dir)
+    out = []
+    if d.is_dir():
+        for fn in sorted(d.glob("*.npz")):
+            parts = fn.stem.split("_")
+            if len(parts) == 3 and parts[1].isdigit() and parts[2].isdigit():
+                out.append((fn, int(parts[1]), int(parts[2])))
+    return out
 
 
 class ReplayBufferStorage:
@@ -36,9 +73,18 @@ class ReplayBufferStorage:
         self._data_specs = data_specs
         self._replay_dir = replay_dir
         self._current_episode = defaultdict(list)
-        self._num_episodes = 0
-        self._num_transitions = 0
+        try:
+            pathlib.Path(replay_dir).mkdir(parents=True, exist_ok=True)      # replay_buffer.py:38
+        except OSError:
+            pass
+        self._preload()
         _entry(replay_dir)["specs"] = data_specs
+
+    def _preload(self):
+        """replay_buffer.py:62-67: episodes already on disk count (a resumed run skips the seed phase)"""
+        files = _episode_files(self._replay_dir)
+        self._num_episodes = len(files)
+        self._num_transitions = sum(n for _, _, n in files)
 
     def __len__(self):
         return self._num_transitions
@@ -59,9 +105,13 @@ class ReplayBufferStorage:
         self._store_episode(done)
 
     def _store_episode(self, episode):
+        eps_idx, eps_len = self._num_episodes, episode_len(episode)
         self._num_episodes += 1
-        self._num_transitions += episode_len(episode)
+        self._num_transitions += eps_len
         ent = _entry(self._replay_dir)
+        if ent["save_snapshot"]:                      # replay_buffer.py:69-78 (same file name, same content)
+            ts = datetime.datetime.now().strftime("%Y%m%dT%H%M%S")
+            save_episode(episode, pathlib.Path(self._replay_dir) / f"{ts}_{eps_idx}_{eps_len}.npz")
         if ent["store"] is not None:
             ent["store"].add_episode(episode)
         else:
@@ -101,4 +151,18 @@ def make_replay_loader(replay_dir, max_size, batch_size, num_workers, save_snaps
     if seed is None:
         seed = int(np.random.get_state()[1][0])          # what the reference's _worker_init_fn seeds from
     ent["store"] = DeviceReplay(capacity, obs_shape, action_dim, nstep, discount, device, seed=seed)
+    ent["save_snapshot"] = bool(save_snapshot)
+    # resume: the newest episodes on disk that fit max_size (replay_buffer.py:120-140 walks them newest first),
+    # added oldest first so that eviction order stays chronological
+    keep, size = [], 0
+    for fn, _, n in reversed(_episode_files(replay_dir)):
+        if size + n > int(max_size):
+            break
+        keep.append(fn)
+        size += n
+    for fn in reversed(keep):
+        try:
+            ent["store"].add_episode(load_episode(fn))
+        except (OSError, ValueError, KeyError):
+            continue                                  # an unreadable file is skipped, as the reference does (:104-107)
     return _Loader(replay_dir, ent["store"], batch_size)

@@ -401,10 +401,57 @@ def gen_nstep(ref_rb):
     print("nstep ok", len(out))
 
 
+def gen_ref_state(ref_drq, ref_utils):
+    """A small REFERENCE agent after two of its own updates, saved as plain tensors (module state_dicts and
+    torch.optim.Adam state_dicts; loads with weights_only=True): what tests/test_cpu_interface.py imports into this
+    repo's agent.  The reverse direction is checked right here, in the only place where the reference runs: the
+    export of this repo's agent is loaded by the reference's own objects with their own load_state_dict."""
+    C, A, Fd, H, B = 9, 2, 2, 8, 2
+    torch.manual_seed(3)
+    ag = ref_drq.DrQV2Agent((C, 84, 84), (A,), "cpu", 1e-3, Fd, H, 0.01, 2000, 2, "0.2", 0.3, True)
+    for u in range(2):
+        batch = synth.make_batch(B, A, C, seed=200 + u, smooth=True)
+        ag.update(iter([tuple(x.numpy() for x in batch)]), 2 * u)
+    sd = lambda m: {k: v.detach().clone() for k, v in m.state_dict().items()}
+    out = {"format": "drqv2-reference-state-v1", "dims": {"C": C, "A": A, "F": Fd, "H": H},
+           "encoder": sd(ag.encoder), "actor": sd(ag.actor), "critic": sd(ag.critic),
+           "critic_target": sd(ag.critic_target),
+           "encoder_opt": ag.encoder_opt.state_dict(), "actor_opt": ag.actor_opt.state_dict(),
+           "critic_opt": ag.critic_opt.state_dict()}
+    torch.save(out, os.path.join(HERE, "ref_state.pt"))
+    # reverse direction: this repo's agent -> export -> the reference's objects
+    import importlib
+    sys.modules.pop("utils", None)
+    mine_mod = importlib.import_module("drqv2")            # the drop-in at the repo root (with its own utils)
+    mine = mine_mod.DrQV2Agent((C, 84, 84), (A,), "cpu", 1e-3, Fd, H, 0.01, 2000, 2, "0.2", 0.3, True)
+    mine.import_reference_state(torch.load(os.path.join(HERE, "ref_state.pt"), weights_only=True))
+    exp = mine.export_reference_state()
+    torch.manual_seed(4)
+    other = ref_drq.DrQV2Agent((C, 84, 84), (A,), "cpu", 1e-3, Fd, H, 0.01, 2000, 2, "0.2", 0.3, True)
+    for n in ("encoder", "actor", "critic", "critic_target"):
+        getattr(other, n).load_state_dict(exp[n])
+    for n in ("encoder_opt", "actor_opt", "critic_opt"):
+        getattr(other, n).load_state_dict(exp[n])
+    for n in ("encoder", "actor", "critic", "critic_target"):
+        for (k, a), (_, b) in zip(getattr(ag, n).state_dict().items(), getattr(other, n).state_dict().items()):
+            assert torch.equal(a, b), (n, k)
+    for n in ("encoder_opt", "actor_opt", "critic_opt"):
+        sa, sb = getattr(ag, n).state_dict()["state"], getattr(other, n).state_dict()["state"]
+        assert sa.keys() == sb.keys()
+        for i in sa:
+            assert float(sa[i]["step"]) == float(sb[i]["step"])
+            assert torch.equal(sa[i]["exp_avg"], sb[i]["exp_avg"]) and torch.equal(sa[i]["exp_avg_sq"], sb[i]["exp_avg_sq"])
+    # and the reference keeps training from it
+    batch = synth.make_batch(B, A, C, seed=202, smooth=True)
+    m = other.update(iter([tuple(x.numpy() for x in batch)]), 4)
+    assert all(np.isfinite(v) for v in m.values())
+    print("ref_state.pt written; the reference's agent loaded this repo's export and took an update:", m["critic_loss"])
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "run in the build container (needs /root/reference)"
     ref_drq, ref_utils, ref_rb = load_reference()
-    which = sys.argv[1:] or ["aug", "elementwise", "interface", "cfg", "nstep", "steps"]
+    which = sys.argv[1:] or ["aug", "elementwise", "interface", "cfg", "nstep", "steps", "ref_state"]
     if "aug" in which:
         gen_aug(ref_drq, ref_utils)
     if "elementwise" in which:
@@ -417,3 +464,5 @@ if __name__ == "__main__":
         gen_nstep(ref_rb)
     if "steps" in which:
         gen_steps(ref_drq, ref_utils)
+    if "ref_state" in which:
+        gen_ref_state(ref_drq, ref_utils)

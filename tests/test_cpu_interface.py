@@ -144,6 +144,51 @@ def test_reference_format_snapshot_loads():
             assert torch.equal(eng.adam_v[off:off + m.numel()].cpu(), ref[i]["exp_avg_sq"].reshape(-1))
 
 
+def test_state_written_by_the_reference_loads_and_round_trips():
+    """tests/golden/ref_state.pt was written by the REFERENCE's own agent (make_golden.py gen_ref_state: two of its
+    updates, then module / torch.optim.Adam state_dicts as plain tensors).  It loads with weights_only=True, goes
+    into this agent's arenas, and export_reference_state() gives the same tensors back; make_golden.py also checked,
+    where the reference runs, that the reference's objects load that export and keep training."""
+    import drqv2
+    st = torch.load(os.path.join(ROOT, "tests", "golden", "ref_state.pt"), weights_only=True)
+    d = st["dims"]
+    ag = drqv2.DrQV2Agent((d["C"], 84, 84), (d["A"],), "cpu", 5e-4, d["F"], d["H"], 0.01, 2000, 2, "0.2", 0.3, True)
+    ag.import_reference_state(st)
+    eng = ag._engine
+    assert (ag.encoder_opt.t, ag.actor_opt.t, ag.critic_opt.t) == (2, 2, 2) and ag.critic_opt.lr == 1e-3
+    for name in ("encoder", "actor", "critic", "critic_target"):
+        for k, v in getattr(ag, name).state_dict().items():
+            assert torch.equal(v, st[name][k]), (name, k)
+    for net, on in (("enc", "encoder_opt"), ("actor", "actor_opt"), ("critic", "critic_opt")):
+        for i, off in enumerate(eng.layout[net]):
+            m = st[on]["state"][i]["exp_avg"].reshape(-1)
+            assert torch.equal(eng.adam_m[off:off + m.numel()], m)
+            assert torch.equal(eng.adam_v[off:off + m.numel()], st[on]["state"][i]["exp_avg_sq"].reshape(-1))
+            assert bool(m.abs().sum() > 0)
+    exp = ag.export_reference_state()
+    for name in ("encoder", "actor", "critic", "critic_target"):
+        assert all(torch.equal(exp[name][k], st[name][k]) for k in st[name])
+    for on in ("encoder_opt", "actor_opt", "critic_opt"):
+        assert exp[on]["state"].keys() == st[on]["state"].keys()
+        for i, e in exp[on]["state"].items():
+            assert float(e["step"]) == float(st[on]["state"][i]["step"]) == 2.0
+            assert torch.equal(e["exp_avg"], st[on]["state"][i]["exp_avg"])
+            assert torch.equal(e["exp_avg_sq"], st[on]["state"][i]["exp_avg_sq"])
+    # the export is what a genuine torch.optim.Adam takes (the reference's optimisers are exactly that, drqv2.py:148-150)
+    import io
+    buf = io.BytesIO()
+    torch.save(exp, buf)
+    buf.seek(0)
+    back = torch.load(buf, weights_only=True)                      # nothing but tensors and python scalars inside
+    twin = drqv2.Critic(32 * 35 * 35, (d["A"],), d["F"], d["H"])
+    twin.load_state_dict(back["critic"])
+    opt = torch.optim.Adam(twin.parameters(), lr=5e-4)
+    opt.load_state_dict(back["critic_opt"])
+    assert opt.param_groups[0]["lr"] == 1e-3
+    s0 = opt.state[next(iter(twin.parameters()))]
+    assert float(s0["step"]) == 2.0 and torch.equal(s0["exp_avg"], st["critic_opt"]["state"][0]["exp_avg"])
+
+
 def test_c_abi_exports_every_declared_symbol():
     """include/drqv2_hip.h <-> libdrqv2_hip.so <-> the ctypes prototype table."""
     from drqv2_amd import _lib

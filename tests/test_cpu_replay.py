@@ -91,3 +91,48 @@ def test_storage_and_loader_dropin_names(tmp_path):
     assert store.episodes == [[0, 5]]
     assert torch.equal(store.frames[:5], torch.from_numpy(ep["observation"].reshape(5, 16)))
     assert torch.equal(store.action[:5], torch.from_numpy(ep["action"]))
+
+
+def test_resume_reloads_reference_named_episode_files(tmp_path):
+    """save_snapshot=True: finished episodes are written as <ts>_<idx>_<len>.npz like the reference's storage does,
+    and a NEW storage + loader on the same directory (a resumed run, train.py:199-204) starts with them in the device
+    store: the first update() after load_snapshot() has data.  Only the newest episodes that fit max_size load."""
+    import replay_buffer as rb
+    d = tmp_path / "buffer"
+    specs = (_Spec("observation", OBS, np.uint8), _Spec("action", (2,), np.float32),
+             _Spec("reward", (1,), np.float32), _Spec("discount", (1,), np.float32))
+    st = rb.ReplayBufferStorage(specs, d)
+    rb.make_replay_loader(d, 100, 8, 4, True, 3, 0.99, device="cpu")
+    eps = [episode(4, seed=11), episode(6, seed=12), episode(5, seed=13)]
+    for ep in eps:
+        T1 = ep["observation"].shape[0]
+        for t in range(T1):
+            st.add(_Step(t == T1 - 1, observation=ep["observation"][t], action=ep["action"][t],
+                         reward=ep["reward"][t], discount=ep["discount"][t]))
+    files = sorted(d.glob("*.npz"))
+    assert [f.stem.split("_")[1:] for f in files] == [["0", "4"], ["1", "6"], ["2", "5"]]
+    back = rb.load_episode(files[1])
+    assert all(np.array_equal(back[k], eps[1][k]) for k in eps[1])
+    # "restart": forget the in-memory registry, build storage + loader again on the same directory
+    rb._REGISTRY.clear()
+    st2 = rb.ReplayBufferStorage(specs, d)
+    assert len(st2) == 15 and st2._num_episodes == 3                 # _preload (replay_buffer.py:62-67)
+    rb.make_replay_loader(d, 100, 8, 4, True, 3, 0.99, device="cpu")
+    store = rb._REGISTRY[str(d)]["store"]
+    assert store.episodes == [[0, 5], [5, 7], [12, 6]] and len(store) == 15
+    assert torch.equal(store.frames[5:12], torch.from_numpy(eps[1]["observation"].reshape(7, 16)))
+    # max_size smaller than what is on disk: the newest episodes win
+    rb._REGISTRY.clear()
+    rb.ReplayBufferStorage(specs, d)
+    rb.make_replay_loader(d, 11, 8, 4, True, 3, 0.99, device="cpu")
+    store = rb._REGISTRY[str(d)]["store"]
+    assert len(store) == 11 and torch.equal(store.frames[:7], torch.from_numpy(eps[1]["observation"].reshape(7, 16)))
+    # without save_snapshot nothing is written
+    d2 = tmp_path / "buffer2"
+    st3 = rb.ReplayBufferStorage(specs, d2)
+    rb.make_replay_loader(d2, 100, 8, 4, False, 3, 0.99, device="cpu")
+    ep = eps[0]
+    for t in range(5):
+        st3.add(_Step(t == 4, observation=ep["observation"][t], action=ep["action"][t], reward=ep["reward"][t],
+                      discount=ep["discount"][t]))
+    assert not list(d2.glob("*.npz"))

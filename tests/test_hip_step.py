@@ -328,6 +328,23 @@ def test_gating_and_metric_keys():
     assert run_hip(ag, cfg, 1)[0] == {}
 
 
+def test_metrics_as_device_tensors_option():
+    """SURVEY 8f rank 4: with metrics_on_device the update returns 0-d device tensors (no host wait in update());
+    the reference's Logger.log takes tensors (logger.py:143-144: `value.item()`).  Same values as the float form."""
+    cfg = CASES["small_h64_b6"]
+    a, b = make_agent(cfg), make_agent(cfg)
+    b.metrics_on_device = True
+    for u in range(2):
+        ma, _, _ = run_hip(a, cfg, u)
+        mb, _, _ = run_hip(b, cfg, u)
+        assert list(ma.keys()) == list(mb.keys())
+        assert all(torch.is_tensor(v) and v.dim() == 0 for v in mb.values())
+        assert all(v.is_cuda for k, v in mb.items() if k != "actor_ent")
+        for k in ma:
+            assert float(mb[k].item()) == pytest.approx(ma[k], rel=1e-6, abs=1e-7), (u, k)
+    assert torch.equal(a._engine.params, b._engine.params)
+
+
 def test_rng_draw_order_matches_reference():
     """Without the hook, update() consumes the global generator like the reference."""
     cfg = CASES["small_h64_b6"]
