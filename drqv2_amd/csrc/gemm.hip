@@ -336,6 +336,159 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16-MFMA variant (BASELINE configs[4], "bf16": the MFMA fc path).  Same GemmArgs, operand layouts, split-K
+// partial format and epilogue as gemm_kernel; operands are read as fp32 from global memory, rounded to bf16 (nearest
+// even) on the way into LDS ([row][k], 72-element pitch: aligned, conflict-free 16-byte fragment reads), products are
+// exact, accumulation is fp32 on v_mfma_f32_32x32x16_bf16.  64x64 block tile (2x2 waves of 32x32), k-tile 64.
+// The fused bias gradient (rowsum) sums the UNROUNDED fp32 values.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack_bf16_pair(float lo, float hi) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, v);
+}
+
+constexpr int BF_BM = 64, BF_BK = 64, BF_PD = 36;   // rows per block tile, k per tile, dword pitch of an LDS row
+
+// k-contiguous operand: thread -> (row = tid/4, 16 consecutive k); out-of-range elements are zero
+template <bool V4>
+__device__ __forceinline__ void bf_stage_kc(const float* P, long ld, int row0, int rows, int k0, int kend,
+                                            unsigned* S, int tid) {
+  const int r = tid >> 2, kq = (tid & 3) * 16;
+  const int row = row0 + r;
+  float v[16];
+  if (V4 && row < rows && k0 + kq + 16 <= kend) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(P + (long)row * ld + k0 + kq);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 t = p[i];
+      v[4 * i] = t[0]; v[4 * i + 1] = t[1]; v[4 * i + 2] = t[2]; v[4 * i + 3] = t[3];
+    }
+  } else {
+    const int rc = row < rows ? row : rows - 1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int k = k0 + kq + i;
+      const float t = P[(long)rc * ld + (k < kend ? k : kend - 1)];
+      v[i] = (row < rows && k < kend) ? t : 0.f;
+    }
+  }
+  unsigned* d = S + r * BF_PD + (kq >> 1);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    u32x4_t pk;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pk[e] = pack_bf16_pair(v[h * 8 + 2 * e], v[h * 8 + 2 * e + 1]);
+    *reinterpret_cast<u32x4_t*>(d + h * 4) = pk;
+  }
+}
+
+// row-contiguous operand (element (row, k) at P[k*ld + row]): thread -> (4 consecutive rows, 2 x 2 consecutive k);
+// rs (optional): += the thread's unrounded values per row (bias gradient of a wgrad GEMM)
+template <bool V4>
+__device__ __forceinline__ void bf_stage_rc(const float* P, long ld, int row0, int rows, int k0, int kend,
+                                            unsigned* S, int tid, float* rs) {
+  const int rc = (tid & 15) * 4, kp = tid >> 4;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int kk = 2 * (kp + 16 * p);          // 0..62 within the tile
+    const int k = k0 + kk;
+    float a[4], b[4];
+    if (V4 && row0 + rc + 4 <= rows && k + 1 < kend) {
+      const f32x4 t0 = *reinterpret_cast<const f32x4*>(P + (long)k * ld + row0 + rc);
+      const f32x4 t1 = *reinterpret_cast<const f32x4*>(P + (long)(k + 1) * ld + row0 + rc);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = t0[i]; b[i] = t1[i]; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = row0 + rc + i;
+        const int rr = row < rows ? row : rows - 1;
+        const float t0 = P[(long)(k < kend ? k : kend - 1) * ld + rr];
+        const float t1 = P[(long)(k + 1 < kend ? k + 1 : kend - 1) * ld + rr];
+        a[i] = (row < rows && k < kend) ? t0 : 0.f;
+        b[i] = (row < rows && k + 1 < kend) ? t1 : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      S[(rc + i) * BF_PD + (kk >> 1)] = pack_bf16_pair(a[i], b[i]);
+      if (rs) rs[i] += a[i] + b[i];
+    }
+  }
+}
+
+template <bool A_KC, bool B_KC, bool V4>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) unsigned As[BF_BM * BF_PD];
+  __shared__ __attribute__((aligned(16))) unsigned Bs[BF_BM * BF_PD];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int col = lane & 31, half = lane >> 5;
+  const int z = blockIdx.z;
+  const int batch = z / g.splitk, ks = z - batch * g.splitk;
+  const int m0 = blockIdx.y * BF_BM, n0 = blockIdx.x * BF_BM;
+  const int kbeg = ks * g.kchunk;
+  const int kend = min(g.K, kbeg + g.kchunk);
+  const float* A = g.A[batch];
+  const float* B = g.B[batch];
+  bool do_rs = false;
+  if constexpr (!A_KC) do_rs = g.ep.rowsum[batch] != nullptr && blockIdx.x == 0;
+  float rs[4] = {0.f, 0.f, 0.f, 0.f};
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const unsigned* ap = As + (wm * 32 + col) * BF_PD + half * 4;
+  const unsigned* bp = Bs + (wn * 32 + col) * BF_PD + half * 4;
+  for (int k0 = kbeg; k0 < kend; k0 += BF_BK) {
+    if constexpr (A_KC) bf_stage_kc<V4>(A, g.lda, m0, g.M, k0, kend, As, tid);
+    else bf_stage_rc<V4>(A, g.lda, m0, g.M, k0, kend, As, tid, do_rs ? rs : nullptr);
+    if constexpr (B_KC) bf_stage_kc<V4>(B, g.ldb, n0, g.N, k0, kend, Bs, tid);
+    else bf_stage_rc<V4>(B, g.ldb, n0, g.N, k0, kend, Bs, tid, nullptr);
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < BF_BK / 16; ++kk) {
+      const bf16x8_t a = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(ap + kk * 8));
+      const bf16x8_t b = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(bp + kk * 8));
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  if constexpr (!A_KC) {
+    if (do_rs) {           // 16 k-lanes hold pieces of each row sum: combine in a fixed order through LDS
+      float* red = reinterpret_cast<float*>(As);     // [16 kp][64 rows]
+      const int rc = (tid & 15) * 4, kp = tid >> 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) red[kp * 64 + rc + i] = rs[i];
+      __syncthreads();
+      if (tid < 64 && m0 + tid < g.M) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[q * 64 + tid];
+        g.ep.rowsum[batch][m0 + tid] = t;
+      }
+    }
+  }
+
+  // C/D layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  const int n = n0 + wn * 32 + col;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (m < g.M && n < g.N) {
+      if (g.splitk > 1) g.part[((long)z * g.M + m) * g.N + n] = acc[r];
+      else epilogue_store(g, batch, m, n, acc[r]);
+    }
+  }
+}
+
 __global__ void splitk_reduce_kernel(GemmArgs g) {
   const long mn = (long)g.M * g.N;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -394,6 +547,22 @@ int dispatch(const GemmArgs& g, int a_kc, int b_kc, bool v4, hipStream_t st) {
   return DRQ_EARG;
 }
 
+template <bool A_KC, bool B_KC>
+int launch_bf16(const GemmArgs& g, bool v4, hipStream_t st) {
+  dim3 grid((g.N + BF_BM - 1) / BF_BM, (g.M + BF_BM - 1) / BF_BM, g.nbatch * g.splitk);
+  if (v4) hipLaunchKernelGGL((gemm_bf16_kernel<A_KC, B_KC, true>), grid, dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((gemm_bf16_kernel<A_KC, B_KC, false>), grid, dim3(256), 0, st, g);
+  DRQ_LAUNCH_CHECK();
+  g_last_splitk = g.splitk;
+  if (g.splitk > 1 && !g_leave_partials) {
+    const long mn = (long)g.M * g.N;
+    dim3 rg((unsigned)((mn + 255) / 256), g.nbatch);
+    hipLaunchKernelGGL(splitk_reduce_kernel, rg, dim3(256), 0, st, g);
+    DRQ_LAUNCH_CHECK();
+  }
+  return DRQ_OK;
+}
+
 }  // namespace
 
 // skinny.hip
@@ -409,10 +578,8 @@ int drq_gemm2(int nbatch, const float* const* A, long lda, int a_kc, const float
               float* const* C, long ldc, int M, int N, int K, const float* const* bias, int relu,
               const float* const* aux, int ldaux, float* const* rowsum, hipStream_t st);
 
-extern "C" {
-
-// See include/drqv2_hip.h.  Host arrays of nbatch (<= 8) device pointers; bias/aux/rowsum arrays may be null.
-DRQ_API int drq_gemm_batched_f32(int nbatch, const float* const* A, long lda, int a_kc, const float* const* B, long ldb,
+// bf16 != 0: the bf16-MFMA kernel for every shape (fp32 storage, operands rounded when staged); see gemm_bf16_kernel
+int drq_gemm_batched_any(int bf16, int nbatch, const float* const* A, long lda, int a_kc, const float* const* B, long ldb,
                          int b_kc, float* const* C, long ldc, int M, int N, int K, const float* const* bias, int relu,
                          const float* const* aux, int ldaux, float* const* rowsum, int scatter_hw, int tile,
                          int splitk, float* ws, size_t ws_bytes, hipStream_t st) {
@@ -420,6 +587,40 @@ DRQ_API int drq_gemm_batched_f32(int nbatch, const float* const* A, long lda, in
   for (int b = 0; b < nbatch; ++b)
     if (!A[b] || !B[b] || !C[b]) return DRQ_EARG;
   if (rowsum && a_kc) return DRQ_EARG;
+  if (bf16) {
+    if (!a_kc && b_kc) return DRQ_EARG;
+    const int cus = drq_num_cus();
+    const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64) * nbatch;
+    if (rowsum) splitk = 1;
+    if (splitk == 0) {
+      splitk = 1;
+      if (tiles < 2L * cus && K >= 512) {
+        splitk = (int)((3L * cus + tiles - 1) / tiles);
+        const int maxs = K / 256;                    // keep >= 4 k-tiles per split
+        if (splitk > maxs) splitk = maxs;
+        if (splitk < 1) splitk = 1;
+      }
+    }
+    int kchunk = ((K + splitk - 1) / splitk + 63) / 64 * 64;
+    splitk = (K + kchunk - 1) / kchunk;
+    if (splitk > 1 && (!ws || (size_t)nbatch * splitk * M * N * sizeof(float) > ws_bytes)) return DRQ_EWS;
+    GemmArgs g{};
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    bool v4 = lda % 4 == 0 && ldb % 4 == 0;
+    for (int b = 0; b < nbatch; ++b) {
+      g.A[b] = A[b]; g.B[b] = B[b]; g.C[b] = C[b];
+      g.ep.bias[b] = bias ? bias[b] : nullptr;
+      g.ep.aux[b] = aux ? aux[b] : nullptr;
+      g.ep.rowsum[b] = rowsum ? rowsum[b] : nullptr;
+      v4 = v4 && al16(A[b]) && al16(B[b]);
+    }
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.nbatch = nbatch; g.splitk = splitk; g.kchunk = kchunk; g.part = ws;
+    g.ep.ldaux = ldaux; g.ep.relu = relu; g.ep.scatter_hw = scatter_hw;
+    if (a_kc && b_kc) return launch_bf16<true, true>(g, v4, st);
+    if (a_kc && !b_kc) return launch_bf16<true, false>(g, v4, st);
+    return launch_bf16<false, false>(g, v4, st);
+  }
   // the skinny dgrad shape of the trunk layer (K = feature_dim, N = 39200) has its own kernel; an explicit
   // tile / splitk request keeps the generic path (tests compare the two)
   if (nbatch == 1 && tile == 0 && splitk == 0 && N >= 4096 && N % 32 == 0 && !bias && !relu && a_kc && !b_kc &&
@@ -480,18 +681,40 @@ DRQ_API int drq_gemm_batched_f32(int nbatch, const float* const* A, long lda, in
   return tile == 2 ? dispatch<2, 2>(g, a_kc, b_kc, v4, st) : dispatch<1, 1>(g, a_kc, b_kc, v4, st);
 }
 
-// internal (step.hip): same call, but a split-K result stays in `ws` as partials [nbatch*splitk][M][N] (no bias, no
-// epilogue) and *splitk_out says how many there are per problem; 1 = the result went to C as usual
-DRQ_API int drq_gemm_batched_partial(int nbatch, const float* const* A, long lda, int a_kc, const float* const* B, long ldb,
-                             int b_kc, float* const* C, long ldc, int M, int N, int K, const float* const* bias,
-                             float* ws, size_t ws_bytes, int* splitk_out, hipStream_t st) {
-  // the trunk forward (k-contiguous operands, N <= 64, long K) has its own kernel
+extern "C" {
+
+// See include/drqv2_hip.h.  Host arrays of nbatch (<= 8) device pointers; bias/aux/rowsum arrays may be null.
+DRQ_API int drq_gemm_batched_f32(int nbatch, const float* const* A, long lda, int a_kc, const float* const* B, long ldb,
+                         int b_kc, float* const* C, long ldc, int M, int N, int K, const float* const* bias, int relu,
+                         const float* const* aux, int ldaux, float* const* rowsum, int scatter_hw, int tile,
+                         int splitk, float* ws, size_t ws_bytes, hipStream_t st) {
+  return drq_gemm_batched_any(0, nbatch, A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, bias, relu, aux, ldaux, rowsum,
+                              scatter_hw, tile, splitk, ws, ws_bytes, st);
+}
+
+DRQ_API int drq_gemm_batched_bf16(int nbatch, const float* const* A, long lda, int a_kc, const float* const* B, long ldb,
+                          int b_kc, float* const* C, long ldc, int M, int N, int K, const float* const* bias, int relu,
+                          const float* const* aux, int ldaux, float* const* rowsum, int scatter_hw, int splitk,
+                          float* ws, size_t ws_bytes, hipStream_t st) {
+  return drq_gemm_batched_any(1, nbatch, A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, bias, relu, aux, ldaux, rowsum,
+                              scatter_hw, 0, splitk, ws, ws_bytes, st);
+}
+
+}  // extern "C"
+
+// internal (step.hip): the forward form with the split-K sum left to the caller, in either precision: a split-K
+// result stays in `ws` as partials [nbatch*splitk][M][N] (no bias, no epilogue) and *splitk_out says how many there
+// are per problem; 1 = the result went to C as usual
+int drq_gemm_batched_partial_any(int bf16, int nbatch, const float* const* A, long lda, int a_kc, const float* const* B,
+                                 long ldb, int b_kc, float* const* C, long ldc, int M, int N, int K,
+                                 const float* const* bias, float* ws, size_t ws_bytes, int* splitk_out, hipStream_t st) {
+  // the fp32 trunk forward (k-contiguous operands, N <= 64, long K) has its own kernel
 #ifdef DRQ_DEV
   static const bool no_trunk = getenv("DRQ_NO_TRUNK_KERNEL") != nullptr;     // development build: A/B against the tiled GEMM
 #else
   constexpr bool no_trunk = false;
 #endif
-  if (a_kc && b_kc && N <= 128 && K >= 4096 && ldc == N && !no_trunk) {
+  if (!bf16 && a_kc && b_kc && N <= 128 && K >= 4096 && ldc == N && !no_trunk) {
     int sk = 1;
     const int rc = drq_trunk_fwd_partial(nbatch, A, lda, B, ldb, M, N, K, ws, ws_bytes, &sk, st);
     if (rc == DRQ_OK) {
@@ -502,11 +725,20 @@ DRQ_API int drq_gemm_batched_partial(int nbatch, const float* const* A, long lda
   }
   g_leave_partials = true;
   g_last_splitk = 1;
-  const int rc = drq_gemm_batched_f32(nbatch, A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, bias, 0, nullptr, 0, nullptr,
-                                      0, 1, 0, ws, ws_bytes, st);
+  const int rc = drq_gemm_batched_any(bf16, nbatch, A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, bias, 0, nullptr, 0,
+                                      nullptr, 0, bf16 ? 0 : 1, 0, ws, ws_bytes, st);
   g_leave_partials = false;
   if (splitk_out) *splitk_out = g_last_splitk;
   return rc;
+}
+
+extern "C" {
+
+DRQ_API int drq_gemm_batched_partial(int nbatch, const float* const* A, long lda, int a_kc, const float* const* B, long ldb,
+                             int b_kc, float* const* C, long ldc, int M, int N, int K, const float* const* bias,
+                             float* ws, size_t ws_bytes, int* splitk_out, hipStream_t st) {
+  return drq_gemm_batched_partial_any(0, nbatch, A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, bias, ws, ws_bytes,
+                                      splitk_out, st);
 }
 
 // strided-batch form of the same call

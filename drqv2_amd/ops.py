@@ -79,18 +79,22 @@ def u8_normalize(x):
     return y
 
 
-def conv3x3_fwd(x, w, b, stride, relu=True):
+def conv3x3_fwd(x, w, b, stride, relu=True, bf16=False):
     lib = _lib.load()
     _need(x, name="x"), _need(w, name="w"), _need(b, name="b")
     nb, cin, hin, _ = x.shape
     hout = (hin - 3) // stride + 1
     y = torch.empty((nb, 32, hout, hout), device=x.device, dtype=torch.float32)
+    if bf16:
+        check(lib.drq_conv3x3_fwd_bf16(ptr(x), ptr(w), ptr(b), ptr(y), nb, hin, int(relu), 32 * hout * hout, hout * hout,
+                                       hout, 0, _stream()), "drq_conv3x3_fwd_bf16")
+        return y
     check(lib.drq_conv3x3_fwd(ptr(x), ptr(w), ptr(b), ptr(y), nb, cin, hin, stride, int(relu), 32 * hout * hout,
                               hout * hout, hout, 0, _stream()), "drq_conv3x3_fwd")
     return y
 
 
-def conv3x3_dgrad(dy_pad, w, mask):
+def conv3x3_dgrad(dy_pad, w, mask, bf16=False):
     """dy_pad [nb,32,hout+4,hout+4] (zero border of 2) -> dx [nb,32,hout+2,hout+2] * (mask>0)."""
     lib = _lib.load()
     _need(dy_pad, name="dy_pad"), _need(w, name="w")
@@ -101,12 +105,16 @@ def conv3x3_dgrad(dy_pad, w, mask):
         _need(mask, name="mask")
         assert tuple(mask.shape) == (nb, 32, hin, hin)
     dx = torch.empty((nb, 32, hin, hin), device=dy_pad.device, dtype=torch.float32)
+    if bf16:
+        check(lib.drq_conv3x3_dgrad_bf16(ptr(dy_pad), ptr(w), ptr(mask), ptr(dx), nb, hout, 32 * hin * hin, hin * hin, hin,
+                                         0, _stream()), "drq_conv3x3_dgrad_bf16")
+        return dx
     check(lib.drq_conv3x3_dgrad(ptr(dy_pad), ptr(w), ptr(mask), ptr(dx), nb, hout, 32 * hin * hin, hin * hin, hin, 0,
                                 _stream()), "drq_conv3x3_dgrad")
     return dx
 
 
-def conv3x3_wgrad(x, dy, stride):
+def conv3x3_wgrad(x, dy, stride, bf16=False):
     """x [nb,cin,hin,hin], dy [nb,32,hout,hout] (any strides with unit x-stride) -> dw, db."""
     lib = _lib.load()
     _need(x, name="x")
@@ -117,6 +125,10 @@ def conv3x3_wgrad(x, dy, stride):
     db = torch.empty((32,), device=x.device, dtype=torch.float32)
     nbytes = lib.drq_conv3x3_wgrad_ws_bytes()
     ws = torch.empty((nbytes // 4,), device=x.device, dtype=torch.float32)
+    if bf16:
+        check(lib.drq_conv3x3_wgrad_bf16(ptr(x), dy.data_ptr(), ptr(dw), ptr(db), nb, hin, dy.stride(0), dy.stride(1),
+                                         dy.stride(2), 0, ptr(ws), nbytes, _stream()), "drq_conv3x3_wgrad_bf16")
+        return dw, db
     check(lib.drq_conv3x3_wgrad(ptr(x), dy.data_ptr(), ptr(dw), ptr(db), nb, cin, hin, stride, dy.stride(0),
                                 dy.stride(1), dy.stride(2), 0, ptr(ws), nbytes, _stream()), "drq_conv3x3_wgrad")
     return dw, db
@@ -217,7 +229,7 @@ def _ptr_array(ts):
 
 
 def gemm_batched(As, a_kc, Bs, b_kc, M, N, K, lda, ldb, biases=None, relu=False, auxs=None, rowsum=False, tile=0,
-                 splitk=0, scatter_hw=0, Cs=None):
+                 splitk=0, scatter_hw=0, Cs=None, bf16=False):
     """n independent problems of one shape in a single launch.  Returns (list of C, list of rowsum or None).
     scatter_hw > 0: C_i is a caller-provided zero-padded [M][32][hw+4][hw+4] gradient buffer (pass Cs)."""
     lib = _lib.load()
@@ -227,6 +239,13 @@ def gemm_batched(As, a_kc, Bs, b_kc, M, N, K, lda, ldb, biases=None, relu=False,
         Cs = [torch.empty((M, N), device=dev, dtype=torch.float32) for _ in range(n)]
     rs = [torch.empty((M,), device=dev, dtype=torch.float32) for _ in range(n)] if rowsum else None
     ws = torch.empty((16 * 1024 * 1024,), device=dev, dtype=torch.float32)
+    if bf16:
+        check(lib.drq_gemm_batched_bf16(n, _ptr_array(As), lda, int(a_kc), _ptr_array(Bs), ldb, int(b_kc), _ptr_array(Cs),
+                                        N, M, N, K, _ptr_array(biases) if biases else None, int(relu),
+                                        _ptr_array(auxs) if auxs else None, (auxs[0].shape[-1] if auxs else 0),
+                                        _ptr_array(rs) if rs else None, scatter_hw, splitk, ptr(ws), ws.numel() * 4,
+                                        _stream()), "drq_gemm_batched_bf16")
+        return Cs, rs
     check(lib.drq_gemm_batched_f32(n, _ptr_array(As), lda, int(a_kc), _ptr_array(Bs), ldb, int(b_kc), _ptr_array(Cs),
                                    N, M, N, K, _ptr_array(biases) if biases else None, int(relu),
                                    _ptr_array(auxs) if auxs else None, (auxs[0].shape[-1] if auxs else 0),

@@ -65,6 +65,17 @@ int drq_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, int
                       drq_stream_t stream);
 size_t drq_conv3x3_wgrad_ws_bytes(void);
 
+/* ---- bf16-MFMA variants of the 32->32 channel layers (conv2..4), BASELINE configs[4] ("bf16").  New functionality:
+ * the reference is fp32 only.  Same arguments, layouts and fp32 storage as the entries above; every MFMA operand is
+ * rounded to bf16 (nearest even) when staged, products are exact, accumulation is fp32: the result is the
+ * fp32-accumulated convolution of the bf16-rounded operands.  hin in {41,39,37} (fwd, wgrad); hout+4 in {39,41,43}. */
+int drq_conv3x3_fwd_bf16(const float* x, const float* w, const float* bias, float* y, int nb, int hin, int relu,
+                         long y_bs, long y_cs, long y_rs, long y_off, drq_stream_t stream);
+int drq_conv3x3_dgrad_bf16(const float* dy_pad, const float* w, const float* mask, float* dx, int nb, int hout,
+                           long dx_bs, long dx_cs, long dx_rs, long dx_off, drq_stream_t stream);
+int drq_conv3x3_wgrad_bf16(const float* x, const float* dy, float* dw, float* db, int nb, int hin, long dy_bs,
+                           long dy_cs, long dy_rs, long dy_off, float* ws, size_t ws_bytes, drq_stream_t stream);
+
 /* ---- nn.Linear forward / backward (drqv2.py:74-81,100-111) as one strided, batched GEMM:
  *   C[b][m][n] = epi( sum_k A_b(m,k) * B_b(k,n) ),  epi(v) = relu?(v + bias[n]) * (aux[m][n] > 0)?
  *   a_kc: A(m,k)=A[m*lda+k] else A[k*lda+m];  b_kc: B(k,n)=B[n*ldb+k] else B[k*ldb+n].
@@ -82,6 +93,13 @@ int drq_gemm_batched_f32(int nbatch, const float* const* A, long lda, int a_kc, 
                          int b_kc, float* const* C, long ldc, int M, int N, int K, const float* const* bias, int relu,
                          const float* const* aux, int ldaux, float* const* rowsum, int scatter_hw, int tile,
                          int splitk, float* ws, size_t ws_bytes, drq_stream_t stream);
+
+/* bf16-MFMA variant of drq_gemm_batched_f32 (BASELINE configs[4]; new functionality, see the conv entries): fp32
+ * storage, operands rounded to bf16 when staged, fp32 accumulation; rowsum sums the unrounded values. */
+int drq_gemm_batched_bf16(int nbatch, const float* const* A, long lda, int a_kc, const float* const* B, long ldb,
+                          int b_kc, float* const* C, long ldc, int M, int N, int K, const float* const* bias, int relu,
+                          const float* const* aux, int ldaux, float* const* rowsum, int scatter_hw, int splitk,
+                          float* ws, size_t ws_bytes, drq_stream_t stream);
 
 /* Forward form only (both operands k-contiguous, a_kc = b_kc = 1) with the split-K sum left to the caller: when
  * *splitk_out > 1 the result is ws[(b*splitk + s)*M*N + m*N + n], s < splitk, WITHOUT bias (the consumer, e.g. the

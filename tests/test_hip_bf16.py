@@ -1,0 +1,107 @@
+"""bf16-MFMA kernels (BASELINE configs[4]).  New functionality with no reference semantics beyond "fp32 math, rounded"
+(SURVEY.md section 2.1): parity unpinned by the reference.  What IS pinned: each kernel must equal the fp32-accumulated
+result on operands rounded to bf16 (nearest even) -- checked against fp64 on the rounded operands to 1e-5 normwise --
+and must stay within the stated distance (2e-2 normwise, measured 2-4e-3) of the fp64 result on the unrounded operands."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from drqv2_amd import ops as o
+    return o
+
+
+def r16(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+def gerr(a, b):
+    return float((a.double() - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("hin,nb", [(41, 3), (39, 2), (37, 5), (41, 200)])
+def test_conv_bf16_fwd_dgrad_wgrad(ops, hin, nb):
+    import torch.nn.functional as Fn
+    g = torch.Generator(device="cuda").manual_seed(hin + nb)
+    rn = lambda *sh: torch.randn(*sh, device="cuda", generator=g)
+    hout = hin - 2
+    x, w, b = rn(nb, 32, hin, hin), rn(32, 32, 3, 3) * 0.1, rn(32) * 0.1
+    # forward
+    y = ops.conv3x3_fwd(x, w, b, 1, bf16=True)
+    ref_r = torch.relu(Fn.conv2d(r16(x), r16(w), b.double()))
+    ref = torch.relu(Fn.conv2d(x.double(), w.double(), b.double()))
+    assert gerr(y, ref_r) <= 1e-5, gerr(y, ref_r)
+    assert gerr(y, ref) <= 2e-2
+    # dgrad (layer output size hout; dy stored zero-padded by 2) with ReLU mask
+    dy = rn(nb, 32, hout, hout)
+    dy_pad = torch.zeros(nb, 32, hout + 4, hout + 4, device="cuda")
+    dy_pad[:, :, 2:-2, 2:-2] = dy
+    mask = rn(nb, 32, hin, hin)
+    dx = ops.conv3x3_dgrad(dy_pad, w, mask, bf16=True)
+    gx_r = Fn.conv_transpose2d(r16(dy), r16(w)) * (mask.double() > 0)
+    gx = Fn.conv_transpose2d(dy.double(), w.double()) * (mask.double() > 0)
+    assert gerr(dx, gx_r) <= 1e-5, gerr(dx, gx_r)
+    assert gerr(dx, gx) <= 2e-2
+    # wgrad + bias gradient (the bias gradient sums the UNROUNDED dy)
+    dw, db = ops.conv3x3_wgrad(x, dy_pad[:, :, 2:-2, 2:-2], 1, bf16=True)
+    wd = w.double().requires_grad_(True)
+    (gw_r,) = torch.autograd.grad(Fn.conv2d(r16(x), wd), wd, r16(dy))
+    (gw,) = torch.autograd.grad(Fn.conv2d(x.double(), wd), wd, dy.double())
+    assert gerr(dw, gw_r) <= 1e-5, gerr(dw, gw_r)
+    assert gerr(dw, gw) <= 2e-2
+    assert gerr(db, dy.double().sum((0, 2, 3))) <= 3e-6
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 1024, 1024), (70, 100, 56), (33, 21, 130), (512, 64, 2048)])
+def test_gemm_bf16_three_layouts(ops, M, N, K):
+    """forward (x W^T + b, relu), dgrad (dy W with mask), wgrad (dy^T x with bias gradient): the shapes of the update
+    incl. ragged ones (K = 56 / 62, N = A) and a split-K case."""
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    # forward: A = x [M][K] (k-contiguous), B = w [N][K] (k-contiguous)
+    (y,), _ = ops.gemm_batched([x], True, [w], True, M, N, K, K, K, biases=[b], relu=True, bf16=True)
+    ref_r = torch.relu(r16(x) @ r16(w).T + b.double())
+    ref = torch.relu(x.double() @ w.double().T + b.double())
+    assert gerr(y, ref_r) <= 1e-5, gerr(y, ref_r)
+    assert gerr(y, ref) <= 2e-2
+    # dgrad: dx[M][K] = dy[M][N] w[N][K], masked: A = dy (k = N contiguous), B(k,n) = w[k*ldb + n]
+    dy, mask = rnd(M, N, seed=4), rnd(M, K, seed=5)
+    (dx,), _ = ops.gemm_batched([dy], True, [w], False, M, K, N, N, K, auxs=[mask], bf16=True)
+    gx_r = (r16(dy) @ r16(w)) * (mask.double() > 0)
+    assert gerr(dx, gx_r) <= 1e-5, gerr(dx, gx_r)
+    assert gerr(dx, (dy.double() @ w.double()) * (mask.double() > 0)) <= 2e-2
+    # wgrad: dw[N][K] = dy^T x, db = column sums of dy: A(m=n_out, k=batch) = dy[k*lda + m], B(k, n) = x[k*ldb + n]
+    (dw,), (db,) = ops.gemm_batched([dy], False, [x], False, N, K, M, N, K, rowsum=True, bf16=True)
+    assert gerr(dw, r16(dy).T @ r16(x)) <= 1e-5
+    assert gerr(dw, dy.double().T @ x.double()) <= 2e-2
+    assert gerr(db, dy.double().sum(0)) <= 3e-6
+
+
+def test_gemm_bf16_trunk_shapes(ops):
+    """Linear(39200 -> F): forward with split-K (four problems at once), weight gradient, and the input gradient
+    scattered into the zero-padded conv-gradient layout with the ReLU mask."""
+    B, F, R, hw = 64, 50, 39200, 35
+    feat = [rnd(B, R, seed=10 + i, scale=0.05) for i in range(2)]
+    w = [rnd(F, R, seed=20 + i, scale=R ** -0.5) for i in range(2)]
+    bias = [rnd(F, seed=30 + i) for i in range(2)]
+    ys, _ = ops.gemm_batched(feat, True, w, True, B, F, R, R, R, biases=bias, bf16=True)
+    for i in range(2):
+        assert gerr(ys[i], r16(feat[i]) @ r16(w[i]).T + bias[i].double()) <= 1e-5
+        assert gerr(ys[i], feat[i].double() @ w[i].double().T + bias[i].double()) <= 2e-2
+    dz = rnd(B, F, seed=40)
+    (dw,), (db,) = ops.gemm_batched([dz], False, [feat[0]], False, F, R, B, F, R, rowsum=True, bf16=True)
+    assert gerr(dw, r16(dz).T @ r16(feat[0])) <= 1e-5 and gerr(db, dz.double().sum(0)) <= 3e-6
+    pad = torch.zeros(B, 32, hw + 4, hw + 4, device="cuda")
+    ops.gemm_batched([dz], True, [w[0]], False, B, R, F, F, R, auxs=[feat[0]], scatter_hw=hw, Cs=[pad], bf16=True)
+    want = (r16(dz) @ r16(w[0])) * (feat[0].double() > 0)
+    assert gerr(pad[:, :, 2:-2, 2:-2].reshape(B, R), want) <= 1e-5
+    border = pad.clone()
+    border[:, :, 2:-2, 2:-2] = 0
+    assert not bool(border.any())
