@@ -69,6 +69,10 @@ def parse_args(argv=None):
                          "share the single GPU of a development box (with --devices 0,0)")
     ap.add_argument("--devices", default=None,
                     help="rehearsal only: comma-separated device index per local rank (default: LOCAL_RANK)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="bf16: BASELINE configs[4] -- conv2..4 and the fc GEMMs of the update on the bf16 MFMA (fp32 "
+                         "accumulation and storage).  New functionality, never the headline line: use with "
+                         "--task humanoid_run --batch 2048")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip scaling_base / weak / n1_same_workload")
@@ -112,7 +116,7 @@ class Runner:
     """One agent + one resident synthetic batch; times K updates the way the contract says."""
 
     def __init__(self, task, B_local, B_global, dev, rank, world, dp, exchange="auto", host_batch=False,
-                 device_replay=False):
+                 device_replay=False, dtype="f32"):
         import torch
         import drqv2
         from drqv2_amd import synth
@@ -122,6 +126,9 @@ class Runner:
         self.A, self.F = A, F
         torch.manual_seed(1)
         self.agent = drqv2.DrQV2Agent((9, 84, 84), (A,), dev, lr, F, H, 0.01, 2000, 2, sched, 0.3, True)
+        self.dtype = dtype
+        if dtype == "bf16":
+            self.agent.set_compute_dtype("bf16")
         if dp:
             self.agent.enable_data_parallel(batch_is_global=False, exchange=exchange)
         batch = synth.make_batch(B_local, A, 9, seed=rank, smooth=True)
@@ -185,8 +192,9 @@ class Runner:
                 "dt": dt, "last_metrics": metrics}
 
     def describe(self):
+        prec = "fp32" if self.dtype == "f32" else "bf16 MFMA (conv2-4 + fc GEMMs; fp32 accumulation and storage)"
         return (f"{self.task} batch_size={self.B_local}/GPU ({self.B_global} global) 9x84x84 u8 obs, A={self.A}, "
-                f"feature_dim={self.F}, hidden_dim={H}, fp32, use_tb=True")
+                f"feature_dim={self.F}, hidden_dim={H}, {prec}, use_tb=True")
 
     def close(self):
         self.agent.flush()
@@ -238,7 +246,7 @@ def main():
     A, F, _, _ = TASKS[task]
 
     main_run = Runner(task, B_local, B_global, dev, rank, world, use_dp, args.exchange, args.host_batch,
-                      args.device_replay)
+                      args.device_replay, args.dtype)
     res = main_run.run(args.steps, args.warmup)
     dt = res.pop("dt")
     out = {
@@ -246,7 +254,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
         "ms_per_step_p10_p50_p90": res["ms_per_step_p10_p50_p90"], "ms_per_step_max": res["ms_per_step_max"],
         "higher_is_better": True, "scaling": "strong" if (strong or world == 1) else "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic" + (" (batch copied host->device every update)" if args.host_batch else "")
+        "dtype": args.dtype, "data": "synthetic" + (" (batch copied host->device every update)" if args.host_batch else "")
                                 + (" (batches assembled by the device replay)" if args.device_replay else ""),
         "config": {"workload": main_run.describe(), "parallelism": f"dp{world}", "global_batch": B_global,
                    "backend": ("rccl" if args.backend == "nccl" else "gloo (rehearsal)") if use_dp else None,
@@ -261,7 +269,7 @@ def main():
         out["exchange"] = {"mode": ex.mode, "choice_by_bucket_floats": {str(k): v for k, v in ex.choice.items()},
                            "measured_us_by_bucket_floats": {str(k): v for k, v in ex.timings_us.items()}}
 
-    if not args.no_roofline:
+    if not args.no_roofline and args.dtype == "f32":
         # every rank runs it (the updates inside carry the data-parallel collectives); rank 0 reports
         roof = roofline_conv(main_run.agent, B_local, main_run.it, main_run.step)
         main_run.agent.flush()
@@ -269,7 +277,7 @@ def main():
             out["roofline"] = roof
     main_run.close()
 
-    extras = not (args.no_extras or args.host_batch or args.device_replay or args.dp_schedule)
+    extras = not (args.no_extras or args.host_batch or args.device_replay or args.dp_schedule or args.dtype != "f32")
     k2, w2 = max(20, args.steps // 2), max(5, args.warmup // 2)
     if extras and world == 1 and workload == "config2" and args.task is None:
         # first point of the configs[3] scaling curve, on the same box in the same run
@@ -298,7 +306,7 @@ def main():
                                        "steps": k2, "warmup": w2}
             r.close()
         dist.barrier()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.dtype == "f32":
         out["cpu_baseline"] = cpu_baseline(task, B_local)
     if rank == 0:
         print(json.dumps(out), file=json_out, flush=True)
@@ -311,10 +319,10 @@ def main():
 
 
 def conv_traffic():
-    """HBM-side bytes per launch of the two launches of conv3x3_kernel<32,41,1> at B = 256, as measured by
-    tools/pmc_traffic.sh (separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes) and written, with the commit
-    it was measured at, to profiles/conv_traffic.json.  None when that file is missing."""
-    path = os.path.join(ROOT, "profiles", "conv_traffic.json")
+    """Memory-side KB per launch of the kernels of the bench, as measured by tools/pmc_bench.sh (separate rocprofv3
+    --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over `python bench.py`) and written, with the commit it was measured at, to
+    profiles/kernel_traffic.json.  None when that file is missing."""
+    path = os.path.join(ROOT, "profiles", "kernel_traffic.json")
     try:
         with open(path) as f:
             return json.load(f)
@@ -351,13 +359,15 @@ def roofline_conv(agent, B, it, step):
     t_d /= n
     traffic, note = None, None
     tr = conv_traffic()
-    if tr is not None and B == tr.get("B"):
-        per = [(2 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024 for v in tr["launches"].values()]
+    names = ("conv3x3_kernel<32, 41, 1, 2, 1, 0, false>", "conv3x3_kernel<32, 41, 1, 2, 1, 0, true>")   # fwd 2B, dgrad B
+    if tr is not None and B == tr.get("B") and all(n in tr.get("kernels", {}) for n in names):
+        per = [(2 * tr["kernels"][n]["FETCH_SIZE_KB"] + tr["kernels"][n]["WRITE_SIZE_KB"]) * 1024 for n in names]
         traffic = sum(per) / len(per)
-        note = (f"bytes per launch, mean of the two launches, (2*FETCH_SIZE+WRITE_SIZE)*1024 from separate --pmc passes at "
-                f"B={tr['B']} (profiles/conv_traffic.json, measured at commit {tr.get('commit')}); algorithmic bytes are "
-                "210 MB (fwd) / 155 MB (dgrad); the x2 on FETCH_SIZE is calibrated for 16-byte lane loads, this kernel "
-                "uses 12-byte ones")
+        note = (f"bytes per launch, mean of the two launches, (2*FETCH_SIZE+WRITE_SIZE)*1024 from separate --pmc passes of "
+                f"the bench at B={tr['B']} (profiles/kernel_traffic.json, measured at commit {tr.get('commit')}); "
+                "algorithmic bytes are 210 MB (fwd) / 155 MB (dgrad); the x2 on FETCH_SIZE is calibrated for 16-byte lane "
+                "loads, this kernel uses 12-byte ones (F+W alone: "
+                f"{sum((tr['kernels'][n]['FETCH_SIZE_KB'] + tr['kernels'][n]['WRITE_SIZE_KB']) * 1024 for n in names) / 2 / 1e6:.0f} MB)")
     fl_f = 2 * 32 * 288 * (2 * B) * 39 * 39
     fl_d = 2 * 32 * 288 * B * 39 * 39
     ach = (fl_f + fl_d) / (t_f + t_d) / 1e12

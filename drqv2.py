@@ -146,6 +146,16 @@ class DrQV2Agent:
         self.train()
         self.critic_target.train()
 
+    def set_compute_dtype(self, dtype):
+        """"fp32" (default: the reference's arithmetic) or "bf16" (BASELINE configs[4]; new functionality): the update's
+        conv2..4 and nn.Linear GEMMs run on the bf16 MFMA with fp32 accumulation and fp32 storage (DrqStep.bf16)."""
+        name = {"fp32": "fp32", "f32": "fp32", "float32": "fp32", torch.float32: "fp32",
+                "bf16": "bf16", "bfloat16": "bf16", torch.bfloat16: "bf16"}.get(dtype)
+        if name is None:
+            raise ValueError(f"compute dtype {dtype!r}: 'fp32' or 'bf16'")
+        self._engine.bf16 = name == "bf16"
+        return self
+
     def train(self, training=True):
         self.training = training
         self.encoder.train(training)

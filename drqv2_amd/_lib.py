@@ -29,6 +29,7 @@ class DrqStep(C.Structure):
         ("stream", stream_t),
         ("sums_host", c_float_p),
         ("store_aug_next", C.c_int),
+        ("bf16", C.c_int),
         ("timing_events", C.POINTER(C.c_void_p)),
     ]
 
@@ -106,7 +107,7 @@ def load(dev=False):
         fn = getattr(lib, name)       # AttributeError = ABI mismatch, also loud
         fn.restype = res
         fn.argtypes = args
-    if lib.drq_abi_version() != 4:
+    if lib.drq_abi_version() != 5:
         raise DrqError("libdrqv2_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

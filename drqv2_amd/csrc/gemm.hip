@@ -354,13 +354,14 @@ __device__ __forceinline__ unsigned pack_bf16_pair(float lo, float hi) {
 
 constexpr int BF_BM = 64, BF_BK = 64, BF_PD = 36;   // rows per block tile, k per tile, dword pitch of an LDS row
 
+// Staging is split into a LOAD (global fp32 -> 16 registers, issued one k-tile ahead so that it flies under the
+// MFMAs of the current tile) and a STORE (round to bf16, write LDS).
 // k-contiguous operand: thread -> (row = tid/4, 16 consecutive k); out-of-range elements are zero
 template <bool V4>
-__device__ __forceinline__ void bf_stage_kc(const float* P, long ld, int row0, int rows, int k0, int kend,
-                                            unsigned* S, int tid) {
+__device__ __forceinline__ void bf_load_kc(const float* P, long ld, int row0, int rows, int k0, int kend,
+                                           float (&v)[16], int tid) {
   const int r = tid >> 2, kq = (tid & 3) * 16;
   const int row = row0 + r;
-  float v[16];
   if (V4 && row < rows && k0 + kq + 16 <= kend) {
     const f32x4* p = reinterpret_cast<const f32x4*>(P + (long)row * ld + k0 + kq);
 #pragma unroll
@@ -377,6 +378,9 @@ __device__ __forceinline__ void bf_stage_kc(const float* P, long ld, int row0, i
       v[i] = (row < rows && k < kend) ? t : 0.f;
     }
   }
+}
+__device__ __forceinline__ void bf_store_kc(const float (&v)[16], unsigned* S, int tid) {
+  const int r = tid >> 2, kq = (tid & 3) * 16;
   unsigned* d = S + r * BF_PD + (kq >> 1);
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -387,22 +391,20 @@ __device__ __forceinline__ void bf_stage_kc(const float* P, long ld, int row0, i
   }
 }
 
-// row-contiguous operand (element (row, k) at P[k*ld + row]): thread -> (4 consecutive rows, 2 x 2 consecutive k);
-// rs (optional): += the thread's unrounded values per row (bias gradient of a wgrad GEMM)
+// row-contiguous operand (element (row, k) at P[k*ld + row]): thread -> (4 consecutive rows, 2 x 2 consecutive k):
+// v[p*8 + i] = (row i, k), v[p*8 + 4 + i] = (row i, k+1) of pass p
 template <bool V4>
-__device__ __forceinline__ void bf_stage_rc(const float* P, long ld, int row0, int rows, int k0, int kend,
-                                            unsigned* S, int tid, float* rs) {
+__device__ __forceinline__ void bf_load_rc(const float* P, long ld, int row0, int rows, int k0, int kend,
+                                           float (&v)[16], int tid) {
   const int rc = (tid & 15) * 4, kp = tid >> 4;
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
-    const int kk = 2 * (kp + 16 * p);          // 0..62 within the tile
-    const int k = k0 + kk;
-    float a[4], b[4];
+    const int k = k0 + 2 * (kp + 16 * p);
     if (V4 && row0 + rc + 4 <= rows && k + 1 < kend) {
       const f32x4 t0 = *reinterpret_cast<const f32x4*>(P + (long)k * ld + row0 + rc);
       const f32x4 t1 = *reinterpret_cast<const f32x4*>(P + (long)(k + 1) * ld + row0 + rc);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { a[i] = t0[i]; b[i] = t1[i]; }
+      for (int i = 0; i < 4; ++i) { v[p * 8 + i] = t0[i]; v[p * 8 + 4 + i] = t1[i]; }
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -410,14 +412,22 @@ __device__ __forceinline__ void bf_stage_rc(const float* P, long ld, int row0, i
         const int rr = row < rows ? row : rows - 1;
         const float t0 = P[(long)(k < kend ? k : kend - 1) * ld + rr];
         const float t1 = P[(long)(k + 1 < kend ? k + 1 : kend - 1) * ld + rr];
-        a[i] = (row < rows && k < kend) ? t0 : 0.f;
-        b[i] = (row < rows && k + 1 < kend) ? t1 : 0.f;
+        v[p * 8 + i] = (row < rows && k < kend) ? t0 : 0.f;
+        v[p * 8 + 4 + i] = (row < rows && k + 1 < kend) ? t1 : 0.f;
       }
     }
+  }
+}
+// rs (optional): += the thread's unrounded values per row (bias gradient of a wgrad GEMM)
+__device__ __forceinline__ void bf_store_rc(const float (&v)[16], unsigned* S, int tid, float* rs) {
+  const int rc = (tid & 15) * 4, kp = tid >> 4;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int kk = 2 * (kp + 16 * p);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      S[(rc + i) * BF_PD + (kk >> 1)] = pack_bf16_pair(a[i], b[i]);
-      if (rs) rs[i] += a[i] + b[i];
+      S[(rc + i) * BF_PD + (kk >> 1)] = pack_bf16_pair(v[p * 8 + i], v[p * 8 + 4 + i]);
+      if (rs) rs[i] += v[p * 8 + i] + v[p * 8 + 4 + i];
     }
   }
 }
@@ -446,12 +456,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const unsigned* ap = As + (wm * 32 + col) * BF_PD + half * 4;
   const unsigned* bp = Bs + (wn * 32 + col) * BF_PD + half * 4;
+  float va[16], vb[16];
+  auto fetch = [&](int k0) {
+    if constexpr (A_KC) bf_load_kc<V4>(A, g.lda, m0, g.M, k0, kend, va, tid);
+    else bf_load_rc<V4>(A, g.lda, m0, g.M, k0, kend, va, tid);
+    if constexpr (B_KC) bf_load_kc<V4>(B, g.ldb, n0, g.N, k0, kend, vb, tid);
+    else bf_load_rc<V4>(B, g.ldb, n0, g.N, k0, kend, vb, tid);
+  };
+  if (kbeg < kend) fetch(kbeg);
   for (int k0 = kbeg; k0 < kend; k0 += BF_BK) {
-    if constexpr (A_KC) bf_stage_kc<V4>(A, g.lda, m0, g.M, k0, kend, As, tid);
-    else bf_stage_rc<V4>(A, g.lda, m0, g.M, k0, kend, As, tid, do_rs ? rs : nullptr);
-    if constexpr (B_KC) bf_stage_kc<V4>(B, g.ldb, n0, g.N, k0, kend, Bs, tid);
-    else bf_stage_rc<V4>(B, g.ldb, n0, g.N, k0, kend, Bs, tid, nullptr);
+    if constexpr (A_KC) bf_store_kc(va, As, tid);
+    else bf_store_rc(va, As, tid, do_rs ? rs : nullptr);
+    if constexpr (B_KC) bf_store_kc(vb, Bs, tid);
+    else bf_store_rc(vb, Bs, tid, nullptr);
     __syncthreads();
+    if (k0 + BF_BK < kend) fetch(k0 + BF_BK);            // in flight under this tile's MFMAs
 #pragma unroll
     for (int kk = 0; kk < BF_BK / 16; ++kk) {
       const bf16x8_t a = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(ap + kk * 8));

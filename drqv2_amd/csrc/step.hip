@@ -36,6 +36,17 @@ extern "C" int drq_actor_loss_ex(const float* q1, const float* q2, const float* 
 extern "C" int drq_adam_flat2(float* p0, const float* g0, float* m0, float* v0, long n0, long step0, float* p1,
                               const float* g1, float* m1, float* v1, long n1, long step1, double lr, float gscale,
                               hipStream_t st);
+// gemm.hip (internal): either precision (bf16 != 0: bf16-MFMA kernel, fp32 storage)
+int drq_gemm_batched_any(int bf16, int nbatch, const float* const* A, long lda, int a_kc, const float* const* B, long ldb,
+                         int b_kc, float* const* C, long ldc, int M, int N, int K, const float* const* bias, int relu,
+                         const float* const* aux, int ldaux, float* const* rowsum, int scatter_hw, int tile,
+                         int splitk, float* ws, size_t ws_bytes, hipStream_t st);
+int drq_gemm_batched_partial_any(int bf16, int nbatch, const float* const* A, long lda, int a_kc, const float* const* B,
+                                 long ldb, int b_kc, float* const* C, long ldc, int M, int N, int K,
+                                 const float* const* bias, float* ws, size_t ws_bytes, int* splitk_out, hipStream_t st);
+// conv_bf16.hip (internal)
+int drq_conv3x3_wgrad_partial_bf16(const float* x, const float* dy, int nb, int hin, long dy_bs, long dy_cs, long dy_rs,
+                                   long dy_off, float* part, size_t part_bytes, int* nblocks, hipStream_t st);
 // conv.hip (internal)
 int drq_conv3x3_wgrad_partial(const float* x, const float* dy, int nb, int cin, int hin, int stride, long dy_bs,
                               long dy_cs, long dy_rs, long dy_off, float* part, size_t part_bytes, int* nblocks,
@@ -206,25 +217,26 @@ struct Ctx {
   float* ws(int id) const { return s->ws + W.off[id]; }
   float* p(long off) const { return s->params + off; }
   float* g(long off) const { return s->grads + off; }
+  int bf16() const { return s->bf16 ? 1 : 0; }
   float* gemm_ws() const { return ws(W_GEMM_WS); }
   size_t gemm_ws_bytes() const { return (size_t)16 * 1024 * 1024 * sizeof(float); }
 
   // n problems  y_i = act(x_i W_i^T + b_i)
   int fwd(int n, const float* const* x, long ldx, const float* const* w, const float* const* b, float* const* y,
           long ldy, int M, int N, int K, int relu) const {
-    return drq_gemm_batched_f32(n, x, ldx, 1, w, K, 1, y, ldy, M, N, K, b, relu, nullptr, 0, nullptr, 0, 0, 0,
+    return drq_gemm_batched_any(bf16(), n, x, ldx, 1, w, K, 1, y, ldy, M, N, K, b, relu, nullptr, 0, nullptr, 0, 0, 0,
                                 gemm_ws(), gemm_ws_bytes(), st);
   }
   // n problems  dx_i = (dy_i W_i) * (mask_i > 0);  W_i is [K][ldw] row-major, the first Nout columns are used
   int dgrad(int n, const float* const* dy, long lddy, const float* const* w, long ldw, float* const* dx, long lddx,
             int M, int Nout, int K, const float* const* mask, int ldmask) const {
-    return drq_gemm_batched_f32(n, dy, lddy, 1, w, ldw, 0, dx, lddx, M, Nout, K, nullptr, 0, mask, ldmask, nullptr, 0,
+    return drq_gemm_batched_any(bf16(), n, dy, lddy, 1, w, ldw, 0, dx, lddx, M, Nout, K, nullptr, 0, mask, ldmask, nullptr, 0,
                                 0, 0, gemm_ws(), gemm_ws_bytes(), st);
   }
   // n problems  dW_i = dy_i^T x_i ([N][K] row-major), db_i = column sums of dy_i (fused)
   int wgrad(int n, const float* const* dy, long lddy, const float* const* x, long ldx, float* const* dw,
             float* const* db, int Brows, int N, int K) const {
-    return drq_gemm_batched_f32(n, dy, lddy, 0, x, ldx, 0, dw, K, N, K, Brows, nullptr, 0, nullptr, 0, db, 0, 0, 0,
+    return drq_gemm_batched_any(bf16(), n, dy, lddy, 0, x, ldx, 0, dw, K, N, K, Brows, nullptr, 0, nullptr, 0, db, 0, 0, 0,
                                 gemm_ws(), gemm_ws_bytes(), st);
   }
 };
@@ -239,6 +251,10 @@ int encoder_forward(const Ctx& c, const float* x, int nb, float* a1, float* a2, 
   for (int l = x ? 0 : 1; l < 4; ++l) {
     const int hin = kEncH[l], hout = kEncH[l + 1];
     if (ev && l == 1 && hipEventRecord((hipEvent_t)ev[0], c.st) != hipSuccess) return DRQ_EARG;
+    if (c.bf16() && l > 0)
+      CK(drq_conv3x3_fwd_bf16(in, c.p(P.enc_w[l]), c.p(P.enc_b[l]), outs[l], nb, hin, 1, 32L * hout * hout,
+                              (long)hout * hout, hout, 0, c.st));
+    else
     CK(drq_conv3x3_fwd(in, c.p(P.enc_w[l]), c.p(P.enc_b[l]), outs[l], nb, l == 0 ? c.s->C : 32, hin, l == 0 ? 2 : 1,
                        1, 32L * hout * hout, (long)hout * hout, hout, 0, c.st));
     if (ev && l == 1 && hipEventRecord((hipEvent_t)ev[1], c.st) != hipSuccess) return DRQ_EARG;
@@ -346,7 +362,7 @@ int phase_critic_heads(const Ctx& c) {
     float* y[4] = {z4, z4 + (long)B * F, z4 + 2L * B * F, z4 + 3L * B * F};
     // the GEMM leaves its split-K partials in the workspace: the LayerNorm kernel sums them (+ bias) itself
     int sk = 1;
-    CK(drq_gemm_batched_partial(4, x, R, 1, w, R, 1, y, F, B, F, (int)R, b, c.gemm_ws(), c.gemm_ws_bytes(), &sk, st));
+    CK(drq_gemm_batched_partial_any(c.bf16(), 4, x, R, 1, w, R, 1, y, F, B, F, (int)R, b, c.gemm_ws(), c.gemm_ws_bytes(), &sk, st));
     const float* zz[4] = {y[0], y[1], y[2], y[3]};
     const float* gm[4] = {c.p(cr.ln_g), c.p(ac.ln_g), c.p(ac.ln_g), c.p(tg.ln_g)};
     const float* bt[4] = {c.p(cr.ln_b), c.p(ac.ln_b), c.p(ac.ln_b), c.p(tg.ln_b)};
@@ -416,7 +432,7 @@ int phase_critic_heads(const Ctx& c) {
     // layer 1 (input = [h, action], shared by both heads)
     CK(c.wgrad(2, dc1c, H, hac, FA, gw0, gb0, B, H, FA));
     // the split-K partials of this dgrad stay in the workspace: the LayerNorm backward sums them (both heads)
-    CK(drq_gemm_batched_partial(2, dc1c, H, 1, w0, FA, 0, dha, FA, B, FA, H, nullptr, c.gemm_ws(), c.gemm_ws_bytes(),
+    CK(drq_gemm_batched_partial_any(c.bf16(), 2, dc1c, H, 1, w0, FA, 0, dha, FA, B, FA, H, nullptr, c.gemm_ws(), c.gemm_ws_bytes(),
                                 &sk_dha, st));
   }
   // trunk: LayerNorm+tanh backward, then Linear(R -> F)
@@ -428,7 +444,7 @@ int phase_critic_heads(const Ctx& c) {
     float *gw[1] = {c.g(cr.trunk_w)}, *gb[1] = {c.g(cr.trunk_b)}, *dy4[1] = {c.ws(W_DY4)};
     CK(c.wgrad(1, dz, F, x, R, gw, gb, B, F, (int)R));
     // d feat = dz W_t, masked by relu(conv4) and scattered into the padded conv-gradient layout
-    CK(drq_gemm_batched_f32(1, dz, F, 1, w, R, 0, dy4, 0, B, (int)R, F, nullptr, 0, mk, (int)R, nullptr, 35, 0, 0,
+    CK(drq_gemm_batched_any(c.bf16(), 1, dz, F, 1, w, R, 0, dy4, 0, B, (int)R, F, nullptr, 0, mk, (int)R, nullptr, 35, 0, 0,
                             c.gemm_ws(), c.gemm_ws_bytes(), st));
   }
 
@@ -454,6 +470,10 @@ int phase_conv_backward(const Ctx& c) {
     const int hin = kEncH[l], hout = kEncH[l + 1], hp = hout + 4;
     const float* dy = c.ws(dyid[l]);
     float* part = cws + (size_t)l * (quarter / sizeof(float));
+    if (c.bf16() && l > 0)
+      CK(drq_conv3x3_wgrad_partial_bf16(c.ws(actid[l]), dy, B, hin, 32L * hp * hp, (long)hp * hp, hp, 2L * hp + 2, part,
+                                        quarter, &nblk[l], st));
+    else
     CK(drq_conv3x3_wgrad_partial(c.ws(actid[l]), dy, B, l == 0 ? C : 32, hin, l == 0 ? 2 : 1, 32L * hp * hp,
                                  (long)hp * hp, hp, 2L * hp + 2, part, quarter, &nblk[l], st));
     parts[l] = part; cins[l] = l == 0 ? C : 32; dws[l] = c.g(P.enc_w[l]); dbs[l] = c.g(P.enc_b[l]);
@@ -461,6 +481,10 @@ int phase_conv_backward(const Ctx& c) {
       const int hpi = hin + 4;   // padded size of the next (shallower) gradient buffer
       void* const* ev = s->timing_events;
       if (ev && l == 2 && hipEventRecord((hipEvent_t)ev[2], st) != hipSuccess) return DRQ_EARG;
+      if (c.bf16())
+        CK(drq_conv3x3_dgrad_bf16(dy, c.p(P.enc_w[l]), c.ws(actid[l]), c.ws(dyid[l - 1]), B, hout, 32L * hpi * hpi,
+                                  (long)hpi * hpi, hpi, 2L * hpi + 2, st));
+      else
       CK(drq_conv3x3_dgrad(dy, c.p(P.enc_w[l]), c.ws(actid[l]), c.ws(dyid[l - 1]), B, hout, 32L * hpi * hpi,
                            (long)hpi * hpi, hpi, 2L * hpi + 2, st));
       if (ev && l == 2 && hipEventRecord((hipEvent_t)ev[3], st) != hipSuccess) return DRQ_EARG;
@@ -508,7 +532,7 @@ int phase_actor_forward(const Ctx& c) {
     const float *x[1] = {feat_obs}, *w[1] = {c.p(cr.trunk_w)}, *b[1] = {c.p(cr.trunk_b)};
     float* y[1] = {c.ws(W_Z_C2)};
     int sk = 1;
-    CK(drq_gemm_batched_partial(1, x, R, 1, w, R, 1, y, F, B, F, (int)R, b, c.gemm_ws(), c.gemm_ws_bytes(), &sk, st));
+    CK(drq_gemm_batched_partial_any(c.bf16(), 1, x, R, 1, w, R, 1, y, F, B, F, (int)R, b, c.gemm_ws(), c.gemm_ws_bytes(), &sk, st));
     const float *zz[1] = {y[0]}, *gm[1] = {c.p(cr.ln_g)}, *bt[1] = {c.p(cr.ln_b)};
     float* out[1] = {c.ws(W_HA_C2)};
     const int ldo[1] = {FA};
@@ -555,7 +579,7 @@ int phase_actor_backward(const Ctx& c) {
     // action columns of layer 1 only; with the fused output-layer backward the split-K partials stay in the
     // workspace and that kernel sums them
     if (fused_head)
-      CK(drq_gemm_batched_partial(2, dc1c, H, 1, w0a, FA, 0, da, A, B, A, H, nullptr, c.gemm_ws(), c.gemm_ws_bytes(),
+      CK(drq_gemm_batched_partial_any(c.bf16(), 2, dc1c, H, 1, w0a, FA, 0, da, A, B, A, H, nullptr, c.gemm_ws(), c.gemm_ws_bytes(),
                                   &sk_da, st));
     else
       CK(c.dgrad(2, dc1c, H, w0a, FA, da, A, B, A, H, nullptr, 0));
@@ -582,7 +606,7 @@ int phase_actor_backward(const Ctx& c) {
     CK(c.wgrad(1, dp2c, H, p1, H, gw1, gb1, B, H, H));
     CK(c.dgrad(1, dp2c, H, w1, H, dp1, H, B, H, H, p1, H));
     CK(c.wgrad(1, dp1c, H, h, F, gw0, gb0, B, H, F));
-    CK(drq_gemm_batched_partial(1, dp1c, H, 1, w0, F, 0, dh, F, B, F, H, nullptr, c.gemm_ws(), c.gemm_ws_bytes(), &sk_dh,
+    CK(drq_gemm_batched_partial_any(c.bf16(), 1, dp1c, H, 1, w0, F, 0, dh, F, B, F, H, nullptr, c.gemm_ws(), c.gemm_ws_bytes(), &sk_dh,
                                 st));
   }
   CK(drq_ln_tanh_bwd_part(c.ws(W_DH_A), F, nullptr, 0, c.ws(W_HROWS), F, c.ws(W_XHAT_A), c.ws(W_RSTD_A), c.p(ac.ln_g),
@@ -625,7 +649,7 @@ int check_step(const DrqStep* s) {
 
 extern "C" {
 
-DRQ_API int drq_abi_version(void) { return 4; }
+DRQ_API int drq_abi_version(void) { return 5; }
 
 DRQ_API int drq_param_layout(int C, int A, int F, int H, long* out, int cap) {
   if (!out || cap < DRQ_PARAM_LAYOUT_LEN || C <= 0 || A <= 0 || F <= 0 || H <= 0) return DRQ_EARG;

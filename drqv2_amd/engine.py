@@ -240,6 +240,7 @@ class StepEngine:
         self._timing_array = None # ctypes array of 4 hipEvent_t (set_timing_events)
         self._side = None         # side stream of the metric-sums exchange
         self._side_busy = False
+        self.bf16 = False             # DrqStep.bf16: the update's convs / GEMMs on the bf16 MFMA (set_compute_dtype)
         self.store_aug_next = False   # verification: keep the next_obs view's encoder input too (DrqStep.store_aug_next)
         self.world = 1
         self.rank = 0
@@ -377,6 +378,7 @@ class StepEngine:
         d.stream = self._stream()
         d.sums_host = ptr(self.sums_host) if (self.pg is None and self.sums_host is not None) else None
         d.store_aug_next = int(self.store_aug_next)
+        d.bf16 = int(self.bf16)
         d.timing_events = self._timing_array      # None, or 4 hipEvent_t for bench.py's roofline
         return d
 
@@ -481,6 +483,7 @@ class StepEngine:
         n = obs_u8.shape[0]
         B = self._ws_B if (self._ws_B is not None and 2 * self._ws_B >= n) else max(1, (n + 1) // 2)
         d = self.make_desc(B, B, 1.0, 0.0, 0.0, (1, 1, 1))
+        d.bf16 = 0                                  # acting stays in fp32 (DrqStep.bf16)
         mu = torch.empty((n, self.A), device=self.device, dtype=torch.float32)
         with torch.cuda.device(self.device):
             check(lib.drq_act_forward(ctypes.byref(d), ptr(obs_u8), n, ptr(mu)), "drq_act_forward")

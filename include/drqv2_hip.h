@@ -208,6 +208,11 @@ typedef struct {
   int store_aug_next;        /* 0: only the obs view's augmented encoder input is kept in the AUG workspace buffer (rows
                               * [0,B); conv1's weight gradient reads it).  1 (verification): the next_obs view is
                               * stored as well (rows [B,2B)), 65 MB more traffic at B=256. */
+  int bf16;                  /* 0: fp32 everywhere (the reference's arithmetic).  1 (BASELINE configs[4], new functionality):
+                              * conv2..4 forward / dgrad / wgrad and every nn.Linear GEMM of the update run on the bf16
+                              * MFMA (operands rounded to bf16 when staged, fp32 accumulation); storage, the fused
+                              * aug + conv1, conv1's weight gradient, LayerNorm, the output heads, losses, Adam and
+                              * Polyak stay fp32.  act() always runs in fp32. */
   void* const* timing_events; /* optional (may be NULL): host array of 4 hipEvent_t created with timing enabled.
                               * Instrumentation for bench.py's roofline: [0],[1] are recorded on `stream` right
                               * before / after the conv2 forward launch of phase 3, [2],[3] around the conv3 dgrad

@@ -19,7 +19,8 @@ def r16(t):
 
 
 def gerr(a, b):
-    return float((a.double() - b).norm() / b.norm().clamp_min(1e-30))
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
 @pytest.mark.parametrize("hin,nb", [(41, 3), (39, 2), (37, 5), (41, 200)])
@@ -105,3 +106,52 @@ def test_gemm_bf16_trunk_shapes(ops):
     border = pad.clone()
     border[:, :, 2:-2, 2:-2] = 0
     assert not bool(border.any())
+
+
+@pytest.mark.parametrize("name", ["cheetah_b64", "humanoid_b32"])
+def test_bf16_update_against_fp64_oracle(name):
+    """Whole update with set_compute_dtype("bf16") against the fp64 oracle of the reference's fp32 arithmetic, same
+    batch, shifts and noise.  There is no reference behaviour to match here (parity unpinned); the bounds are this
+    implementation's measured distances with a margin: metrics 1e-2 relative; features 2e-2 normwise; gradients by
+    direction and norm -- every weight tensor (>= 1024 elements) cosine >= 0.97 and |g| within 10 %, each network's whole gradient cosine >= 0.98 (measured 0.993 for the encoder).
+    Element-wise agreement is not the criterion: bf16 rounding of the activations flips a fraction of the ReLU
+    decisions near zero, and the bias gradients are small sums of large cancelling terms."""
+    from tests.test_hip_step import WIDE, make_agent, make_oracle, run_hip
+    cfg = WIDE[name]
+    ag = make_agent(cfg).set_compute_dtype("bf16")
+    ref = make_agent(cfg)                                   # the fp32 HIP path on the same inputs
+    o64 = make_oracle(cfg, torch.float64)
+    m, batch, (sh_o, sh_n, n_c, n_a) = run_hip(ag, cfg, 0)
+    m32, _, _ = run_hip(ref, cfg, 0)
+    m64 = o64.update(batch, cfg["step0"], sh_o, sh_n, n_c, n_a, keep=True)
+    worst = 0.0
+    for k in m64:
+        e = abs(m[k] - m64[k]) / max(1.0, abs(m64[k]))
+        worst = max(worst, e)
+        assert e <= 1e-2, (k, m[k], m32[k], m64[k])
+    B = cfg["B"]
+    feat = ag._engine.ws_view("FEAT", B, (2 * B, 39200))
+    ferr = gerr(feat[:B], o64.last["feat"])
+    assert ferr <= 2e-2, ferr
+    cmin, nmax, netcos = 1.0, 0.0, {}
+    cosf = lambda a, b: float(torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-300))
+    for nm, mod, key in (("enc", ag.encoder, "g_enc"), ("critic", ag.critic, "g_critic"), ("actor", ag.actor, "g_actor")):
+        allg, allr = [], []
+        for (pn, p), g64 in zip(mod.named_parameters(), o64.last[key].values()):
+            a, b = p.grad.detach().double().cpu().reshape(-1), g64.reshape(-1)
+            cos = cosf(a, b)
+            nr = abs(float(a.norm() / b.norm().clamp_min(1e-300)) - 1.0)
+            if a.numel() >= 1024:          # biases / scalars are small sums of cancelling terms: whole-network check only
+                cmin, nmax = min(cmin, cos), max(nmax, nr)
+                assert cos >= 0.97 and nr <= 1e-1, (nm, pn, cos, nr)
+            allg.append(a); allr.append(b)
+        netcos[nm] = cosf(torch.cat(allg), torch.cat(allr))
+        # the actor's gradient is taken through the critic AFTER its Adam step at t=1 (a sign-like step that
+        # amplifies every upstream difference: SURVEY finding 3; 1e-3 already in fp32)
+        assert netcos[nm] >= (0.95 if nm == "actor" else 0.98), (nm, netcos[nm])
+    print(f"{name} bf16: worst metric rel err {worst:.2e}, features {ferr:.2e}, min tensor cosine {cmin:.5f}, "
+          f"max norm deviation {nmax:.2e}, whole-network cosines {netcos}")
+    # the parameters moved and stayed finite; a second bf16 update runs from the updated state
+    m2, _, _ = run_hip(ag, cfg, 1)
+    assert all(v == v and abs(v) < 1e6 for v in m2.values())
+    assert bool(torch.isfinite(ag._engine.params).all())
