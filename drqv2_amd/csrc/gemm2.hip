@@ -62,15 +62,15 @@ __device__ __forceinline__ void load_step(float (&v)[16], __amdgpu_buffer_rsrc_t
   }
 }
 
+// bx / batch: the workgroup's position (blockIdx.x / blockIdx.z of a plain launch; gemm2_pair_kernel remaps them)
 template <bool A_KC, bool B_KC, int KS>
-__global__ __launch_bounds__(256) void gemm2_kernel(G2Args g) {
+__device__ __forceinline__ void gemm2_body(const G2Args& g, int bx, int batch) {
   __shared__ float red[KS > 1 ? 3 * 16 * 64 : 1];
   __shared__ float rsred[KS > 1 ? 3 * 32 : 1];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int col = lane & 31, half = lane >> 5;
-  const int batch = blockIdx.z;
   const int NT = g.N >> 5;
-  const int tile = KS > 1 ? blockIdx.x : blockIdx.x * 4 + wid;
+  const int tile = KS > 1 ? bx : bx * 4 + wid;
   const int ntiles = (g.M >> 5) * NT;
   const bool live = tile < ntiles;                 // KS == 1: the last workgroup may hold fewer than 4 tiles
   const int tc = live ? tile : ntiles - 1;
@@ -169,11 +169,31 @@ __global__ __launch_bounds__(256) void gemm2_kernel(G2Args g) {
   }
 }
 
+template <bool A_KC, bool B_KC, int KS>
+__global__ __launch_bounds__(256) void gemm2_kernel(G2Args g) {
+  gemm2_body<A_KC, B_KC, KS>(g, (int)blockIdx.x, (int)blockIdx.z);
+}
+
+// The weight gradient (dW = dy^T x, both operands row-contiguous) and the input gradient (dx = dy W, masked) of ONE
+// layer read the same dy and do not depend on each other: one launch runs both (workgroups [0, nxw) the first,
+// the rest the second) instead of two dependent launches of ~15 us each -- a launch boundary less per layer, and
+// the tail of one problem overlaps the other.  Same bodies as gemm2_kernel: results are bit-identical.
+template <int KSW, int KSD>
+__global__ __launch_bounds__(256) void gemm2_pair_kernel(G2Args gw, G2Args gd, int nxw) {
+  if ((int)blockIdx.x < nxw) gemm2_body<false, false, KSW>(gw, (int)blockIdx.x, (int)blockIdx.z);
+  else gemm2_body<true, false, KSD>(gd, (int)blockIdx.x - nxw, (int)blockIdx.z);
+}
+
+inline bool gemm2_split(const G2Args& g, int nbatch) {
+  const int tiles = (g.M / 32) * (g.N / 32);
+  // split K over the waves of a workgroup when the tiles alone leave the chip under-filled
+  return (long)tiles * nbatch < 4L * drq_num_cus() * 2 && g.K % 128 == 0 && g.K >= 512;
+}
+
 template <bool A_KC, bool B_KC>
 int launch2(const G2Args& g, int nbatch, hipStream_t st) {
   const int tiles = (g.M / 32) * (g.N / 32);
-  // split K over the waves of a workgroup when the tiles alone leave the chip under-filled
-  const bool split = (long)tiles * nbatch < 4L * drq_num_cus() * 2 && g.K % 128 == 0 && g.K >= 512;
+  const bool split = gemm2_split(g, nbatch);
   if (split) {
     hipLaunchKernelGGL((gemm2_kernel<A_KC, B_KC, 4>), dim3(tiles, 1, nbatch), dim3(256), 0, st, g);
   } else {
@@ -475,4 +495,39 @@ int drq_gemm2(int nbatch, const float* const* A, long lda, int a_kc, const float
   if (a_kc && b_kc) return launch2<true, true>(g, nbatch, st);
   if (a_kc && !b_kc) return launch2<true, false>(g, nbatch, st);
   return launch2<false, false>(g, nbatch, st);
+}
+
+// wgrad + dgrad of one hidden layer in one launch (see gemm2_pair_kernel).  dy [Brows][Nout] (ld lddy), x [Brows][Kin],
+// w [Nout][ldw]: dW [Nout][Kin] = dy^T x, db [Nout] = column sums of dy, dx [Brows][Kin] = (dy w) * (mask > 0).
+// Returns DRQ_EARG when a shape is not eligible (the caller then issues the two GEMMs separately).
+int drq_gemm2_wgrad_dgrad(int nbatch, const float* const* dy, long lddy, const float* const* x, long ldx,
+                          float* const* dw, float* const* db, const float* const* w, long ldw, float* const* dx,
+                          long lddx, const float* const* mask, int ldmask, int Brows, int Nout, int Kin, hipStream_t st) {
+  if (nbatch <= 0 || nbatch > MAXB2 || Brows % 32 || Nout % 32 || Kin % 32 || Brows < 64 || Nout < 64 || Kin < 32)
+    return DRQ_EARG;
+  if (lddy % 4) return DRQ_EARG;
+  G2Args gw{}, gd{};
+  for (int b = 0; b < nbatch; ++b) {
+    if (!dy[b] || !x[b] || !dw[b] || !w[b] || !dx[b] || ((uintptr_t)dy[b] & 15)) return DRQ_EARG;
+    gw.A[b] = dy[b]; gw.B[b] = x[b]; gw.C[b] = dw[b]; gw.rowsum[b] = db ? db[b] : nullptr;
+    gd.A[b] = dy[b]; gd.B[b] = w[b]; gd.C[b] = dx[b]; gd.aux[b] = mask ? mask[b] : nullptr;
+  }
+  // wgrad: A(m = n_out, k = row) = dy[k*lddy + m], B(k, n = k_in) = x[k*ldx + n]
+  gw.lda = lddy; gw.ldb = ldx; gw.ldc = Kin; gw.M = Nout; gw.N = Kin; gw.K = Brows;
+  // dgrad: A(m = row, k = n_out) = dy[m*lddy + k], B(k, n = k_in) = w[k*ldw + n]
+  gd.lda = lddy; gd.ldb = ldw; gd.ldc = lddx; gd.ldaux = ldmask; gd.M = Brows; gd.N = Kin; gd.K = Nout;
+  const size_t dyb = (size_t)Brows * lddy * 4, xb = (size_t)Brows * ldx * 4, wb = (size_t)Nout * ldw * 4;
+  if (dyb >= (1ull << 31) || xb >= (1ull << 31) || wb >= (1ull << 31)) return DRQ_EARG;
+  gw.a_bytes = (unsigned)dyb; gw.b_bytes = (unsigned)xb;
+  gd.a_bytes = (unsigned)dyb; gd.b_bytes = (unsigned)wb;
+  const bool sw = gemm2_split(gw, nbatch), sd = gemm2_split(gd, nbatch);
+  const int tw = (gw.M / 32) * (gw.N / 32), td = (gd.M / 32) * (gd.N / 32);
+  const int nxw = sw ? tw : (tw + 3) / 4, nxd = sd ? td : (td + 3) / 4;
+  const dim3 grid(nxw + nxd, 1, nbatch);
+  if (sw && sd) hipLaunchKernelGGL((gemm2_pair_kernel<4, 4>), grid, dim3(256), 0, st, gw, gd, nxw);
+  else if (sw) hipLaunchKernelGGL((gemm2_pair_kernel<4, 1>), grid, dim3(256), 0, st, gw, gd, nxw);
+  else if (sd) hipLaunchKernelGGL((gemm2_pair_kernel<1, 4>), grid, dim3(256), 0, st, gw, gd, nxw);
+  else hipLaunchKernelGGL((gemm2_pair_kernel<1, 1>), grid, dim3(256), 0, st, gw, gd, nxw);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
 }

@@ -44,6 +44,10 @@ int drq_gemm_batched_any(int bf16, int nbatch, const float* const* A, long lda, 
 int drq_gemm_batched_partial_any(int bf16, int nbatch, const float* const* A, long lda, int a_kc, const float* const* B,
                                  long ldb, int b_kc, float* const* C, long ldc, int M, int N, int K,
                                  const float* const* bias, float* ws, size_t ws_bytes, int* splitk_out, hipStream_t st);
+// gemm2.hip (internal): weight gradient + input gradient of one hidden layer in one launch
+int drq_gemm2_wgrad_dgrad(int nbatch, const float* const* dy, long lddy, const float* const* x, long ldx,
+                          float* const* dw, float* const* db, const float* const* w, long ldw, float* const* dx,
+                          long lddx, const float* const* mask, int ldmask, int Brows, int Nout, int Kin, hipStream_t st);
 // conv_bf16.hip (internal)
 int drq_conv3x3_wgrad_partial_bf16(const float* x, const float* dy, int nb, int hin, long dy_bs, long dy_cs, long dy_rs,
                                    long dy_off, float* part, size_t part_bytes, int* nblocks, hipStream_t st);
@@ -239,6 +243,18 @@ struct Ctx {
     return drq_gemm_batched_any(bf16(), n, dy, lddy, 0, x, ldx, 0, dw, K, N, K, Brows, nullptr, 0, nullptr, 0, db, 0, 0, 0,
                                 gemm_ws(), gemm_ws_bytes(), st);
   }
+  // both gradients of one layer (they read the same dy and are independent): one launch when the shape allows
+  int wgrad_dgrad(int n, const float* const* dy, long lddy, const float* const* x, long ldx, float* const* dw,
+                  float* const* db, const float* const* w, long ldw, float* const* dx, long lddx,
+                  const float* const* mask, int ldmask, int Brows, int N, int K) const {
+    if (!bf16()) {
+      const int rc = drq_gemm2_wgrad_dgrad(n, dy, lddy, x, ldx, dw, db, w, ldw, dx, lddx, mask, ldmask, Brows, N, K, st);
+      if (rc != DRQ_EARG) return rc;
+    }
+    const int rc = wgrad(n, dy, lddy, x, ldx, dw, db, Brows, N, K);
+    if (rc != 0) return rc;
+    return dgrad(n, dy, lddy, w, ldw, dx, lddx, Brows, K, N, mask, ldmask);
+  }
 };
 
 // x == nullptr: a1 already holds the first layer's output (fused aug + conv1), start at layer 2
@@ -427,8 +443,7 @@ int phase_critic_heads(const Ctx& c) {
       CK(drq_qout_bwd(2, dq, c2c, w2, dc2, gw2, gb2, B, H, st));
     }
     // layer 2
-    CK(c.wgrad(2, dc2c, H, c1c, H, gw1, gb1, B, H, H));
-    CK(c.dgrad(2, dc2c, H, w1, H, dc1, H, B, H, H, c1c, H));
+    CK(c.wgrad_dgrad(2, dc2c, H, c1c, H, gw1, gb1, w1, H, dc1, H, c1c, H, B, H, H));
     // layer 1 (input = [h, action], shared by both heads)
     CK(c.wgrad(2, dc1c, H, hac, FA, gw0, gb0, B, H, FA));
     // the split-K partials of this dgrad stay in the workspace: the LayerNorm backward sums them (both heads)
@@ -603,8 +618,7 @@ int phase_actor_backward(const Ctx& c) {
       CK(c.wgrad(1, dpre, A, p2, H, gw2, gb2, B, A, H));
       CK(c.dgrad(1, dpre, A, w2, H, dp2, H, B, H, A, p2, H));
     }
-    CK(c.wgrad(1, dp2c, H, p1, H, gw1, gb1, B, H, H));
-    CK(c.dgrad(1, dp2c, H, w1, H, dp1, H, B, H, H, p1, H));
+    CK(c.wgrad_dgrad(1, dp2c, H, p1, H, gw1, gb1, w1, H, dp1, H, p1, H, B, H, H));
     CK(c.wgrad(1, dp1c, H, h, F, gw0, gb0, B, H, F));
     CK(drq_gemm_batched_partial_any(c.bf16(), 1, dp1c, H, 1, w0, F, 0, dh, F, B, F, H, nullptr, c.gemm_ws(), c.gemm_ws_bytes(), &sk_dh,
                                 st));
