@@ -31,12 +31,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TASKS = {   # name: (A, feature_dim, lr, stddev_schedule)  -- cfgs/task/*.yaml of the reference
-    "cheetah_run": (6, 50, 1e-4, "linear(1.0,0.1,500000)"),
-    "quadruped_walk": (12, 50, 1e-4, "linear(1.0,0.1,500000)"),
-    "humanoid_run": (21, 100, 8e-5, "linear(1.0,0.1,2000000)"),
-    "cartpole_swingup": (1, 50, 1e-4, "linear(1.0,0.1,100000)"),
-}
+from drqv2_amd import tasks as _tasks   # the reference's cfgs/ surface as data (one table for benches and tests)
+
+# name: (A, feature_dim, lr, stddev_schedule) as cfgs/config.yaml + cfgs/task/<name>.yaml of the reference resolve
+TASKS = {n: (_tasks.ACTION_DIM[n], _tasks.resolve(n)["feature_dim"], _tasks.resolve(n)["lr"],
+             _tasks.resolve(n)["stddev_schedule"])
+         for n in ("cheetah_run", "quadruped_walk", "humanoid_run", "cartpole_swingup")}
 PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32 matrix == vector peak
 H = 1024
 

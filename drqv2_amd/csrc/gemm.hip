@@ -432,17 +432,19 @@ __device__ __forceinline__ void bf_store_rc(const float (&v)[16], unsigned* S, i
   }
 }
 
-template <bool A_KC, bool B_KC, bool V4>
+// TN: 32-column tiles per wave (block tile 64 x 64*TN).  TN = 2 serves 64 < N <= 128 (the trunk layer at
+// feature_dim 100): the long A operand is then read once instead of once per column tile.
+template <bool A_KC, bool B_KC, bool V4, int TN = 1>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) unsigned As[BF_BM * BF_PD];
-  __shared__ __attribute__((aligned(16))) unsigned Bs[BF_BM * BF_PD];
+  __shared__ __attribute__((aligned(16))) unsigned Bs[TN * BF_BM * BF_PD];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int col = lane & 31, half = lane >> 5;
   const int z = blockIdx.z;
   const int batch = z / g.splitk, ks = z - batch * g.splitk;
-  const int m0 = blockIdx.y * BF_BM, n0 = blockIdx.x * BF_BM;
+  const int m0 = blockIdx.y * BF_BM, n0 = blockIdx.x * (BF_BM * TN);
   const int kbeg = ks * g.kchunk;
   const int kend = min(g.K, kbeg + g.kchunk);
   const float* A = g.A[batch];
@@ -451,31 +453,43 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
   if constexpr (!A_KC) do_rs = g.ep.rowsum[batch] != nullptr && blockIdx.x == 0;
   float rs[4] = {0.f, 0.f, 0.f, 0.f};
 
-  f32x16 acc;
+  f32x16 acc[TN];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   const unsigned* ap = As + (wm * 32 + col) * BF_PD + half * 4;
-  const unsigned* bp = Bs + (wn * 32 + col) * BF_PD + half * 4;
-  float va[16], vb[16];
+  const unsigned* bp = Bs + (wn * 32 * TN + col) * BF_PD + half * 4;
+  float va[16], vb[TN][16];
   auto fetch = [&](int k0) {
     if constexpr (A_KC) bf_load_kc<V4>(A, g.lda, m0, g.M, k0, kend, va, tid);
     else bf_load_rc<V4>(A, g.lda, m0, g.M, k0, kend, va, tid);
-    if constexpr (B_KC) bf_load_kc<V4>(B, g.ldb, n0, g.N, k0, kend, vb, tid);
-    else bf_load_rc<V4>(B, g.ldb, n0, g.N, k0, kend, vb, tid);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      if constexpr (B_KC) bf_load_kc<V4>(B, g.ldb, n0 + j * BF_BM, g.N, k0, kend, vb[j], tid);
+      else bf_load_rc<V4>(B, g.ldb, n0 + j * BF_BM, g.N, k0, kend, vb[j], tid);
+    }
   };
   if (kbeg < kend) fetch(kbeg);
   for (int k0 = kbeg; k0 < kend; k0 += BF_BK) {
     if constexpr (A_KC) bf_store_kc(va, As, tid);
     else bf_store_rc(va, As, tid, do_rs ? rs : nullptr);
-    if constexpr (B_KC) bf_store_kc(vb, Bs, tid);
-    else bf_store_rc(vb, Bs, tid, nullptr);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      if constexpr (B_KC) bf_store_kc(vb[j], Bs + j * BF_BM * BF_PD, tid);
+      else bf_store_rc(vb[j], Bs + j * BF_BM * BF_PD, tid, nullptr);
+    }
     __syncthreads();
     if (k0 + BF_BK < kend) fetch(k0 + BF_BK);            // in flight under this tile's MFMAs
 #pragma unroll
     for (int kk = 0; kk < BF_BK / 16; ++kk) {
       const bf16x8_t a = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(ap + kk * 8));
-      const bf16x8_t b = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(bp + kk * 8));
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const bf16x8_t b =
+            __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(bp + j * 32 * BF_PD + kk * 8));
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+      }
     }
     __syncthreads();
   }
@@ -496,14 +510,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
     }
   }
 
-  // C/D layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-  const int n = n0 + wn * 32 + col;
+  // C/D layout of a 32x32 tile: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-    if (m < g.M && n < g.N) {
-      if (g.splitk > 1) g.part[((long)z * g.M + m) * g.N + n] = acc[r];
-      else epilogue_store(g, batch, m, n, acc[r]);
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + col;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (m < g.M && n < g.N) {
+        if (g.splitk > 1) g.part[((long)z * g.M + m) * g.N + n] = acc[j][r];
+        else epilogue_store(g, batch, m, n, acc[j][r]);
+      }
     }
   }
 }
@@ -568,8 +585,14 @@ int dispatch(const GemmArgs& g, int a_kc, int b_kc, bool v4, hipStream_t st) {
 
 template <bool A_KC, bool B_KC>
 int launch_bf16(const GemmArgs& g, bool v4, hipStream_t st) {
-  dim3 grid((g.N + BF_BM - 1) / BF_BM, (g.M + BF_BM - 1) / BF_BM, g.nbatch * g.splitk);
-  if (v4) hipLaunchKernelGGL((gemm_bf16_kernel<A_KC, B_KC, true>), grid, dim3(256), 0, st, g);
+  // 64 < N <= 128 with a long reduction (the trunk layer at feature_dim 100): one 128-column tile reads A once
+  const bool wide = g.N > 64 && g.N <= 128 && g.K >= 4096;
+  const int bn = wide ? 2 * BF_BM : BF_BM;
+  dim3 grid((g.N + bn - 1) / bn, (g.M + BF_BM - 1) / BF_BM, g.nbatch * g.splitk);
+  if (wide) {
+    if (v4) hipLaunchKernelGGL((gemm_bf16_kernel<A_KC, B_KC, true, 2>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<A_KC, B_KC, false, 2>), grid, dim3(256), 0, st, g);
+  } else if (v4) hipLaunchKernelGGL((gemm_bf16_kernel<A_KC, B_KC, true>), grid, dim3(256), 0, st, g);
   else hipLaunchKernelGGL((gemm_bf16_kernel<A_KC, B_KC, false>), grid, dim3(256), 0, st, g);
   DRQ_LAUNCH_CHECK();
   g_last_splitk = g.splitk;
@@ -584,6 +607,9 @@ int launch_bf16(const GemmArgs& g, bool v4, hipStream_t st) {
 
 }  // namespace
 
+// elementwise.hip (C ABI): out[n] = sum_m dy[m*ld + n]
+extern "C" int drq_colsum(const float* dy, long ld, long dy_bs, float* out, long out_bs, int M, int N, int nbatch,
+                          hipStream_t st);
 // skinny.hip
 int drq_skinny_dgrad(const float* dz, long lda, const float* w, long ldb, float* c, long ldc, int M, int N, int K,
                      const float* aux, int ldaux, int scatter_hw, hipStream_t st);
@@ -610,6 +636,16 @@ int drq_gemm_batched_any(int bf16, int nbatch, const float* const* A, long lda, 
     if (!a_kc && b_kc) return DRQ_EARG;
     const int cus = drq_num_cus();
     const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64) * nbatch;
+    // a weight-gradient GEMM with few output tiles (the first layers: N = feature_dim (+ action_dim)) needs split-K
+    // to fill the chip, and the fused bias gradient cannot be split: it gets its own pass (column sums of dy)
+    if (rowsum && splitk == 0 && tiles < 2L * cus && K >= 512) {
+      for (int b = 0; b < nbatch; ++b)
+        if (rowsum[b]) {
+          const int rc = drq_colsum(A[b], lda, 0, rowsum[b], 0, K, M, 1, st);
+          if (rc != DRQ_OK) return rc;
+        }
+      rowsum = nullptr;
+    }
     if (rowsum) splitk = 1;
     if (splitk == 0) {
       splitk = 1;

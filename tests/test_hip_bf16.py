@@ -85,10 +85,21 @@ def test_gemm_bf16_three_layouts(ops, M, N, K):
     assert gerr(db, dy.double().sum(0)) <= 3e-6
 
 
-def test_gemm_bf16_trunk_shapes(ops):
-    """Linear(39200 -> F): forward with split-K (four problems at once), weight gradient, and the input gradient
-    scattered into the zero-padded conv-gradient layout with the ReLU mask."""
-    B, F, R, hw = 64, 50, 39200, 35
+def test_gemm_bf16_first_layer_wgrad_with_split_k(ops):
+    """Weight gradient of a first layer (few output tiles, long batch reduction): split-K plus a separate column-sum
+    pass for the bias gradient."""
+    Brows, N, K = 2048, 1024, 121
+    dy, x = rnd(Brows, N, seed=50), rnd(Brows, K, seed=51)
+    (dw,), (db,) = ops.gemm_batched([dy], False, [x], False, N, K, Brows, N, K, rowsum=True, bf16=True)
+    assert gerr(dw, r16(dy).T @ r16(x)) <= 1e-5
+    assert gerr(db, dy.double().sum(0)) <= 3e-6
+
+
+@pytest.mark.parametrize("F", [50, 100])
+def test_gemm_bf16_trunk_shapes(ops, F):
+    """Linear(39200 -> F): forward with split-K (several problems at once; F = 100 takes the 128-column tile), weight
+    gradient, and the input gradient scattered into the zero-padded conv-gradient layout with the ReLU mask."""
+    B, R, hw = 64, 39200, 35
     feat = [rnd(B, R, seed=10 + i, scale=0.05) for i in range(2)]
     w = [rnd(F, R, seed=20 + i, scale=R ** -0.5) for i in range(2)]
     bias = [rnd(F, seed=30 + i) for i in range(2)]
