@@ -209,8 +209,10 @@ typedef struct {
                               * [0,B); conv1's weight gradient reads it).  1 (verification): the next_obs view is
                               * stored as well (rows [B,2B)), 65 MB more traffic at B=256. */
   int bf16;                  /* 0: fp32 everywhere (the reference's arithmetic).  1 (BASELINE configs[4], new functionality):
-                              * conv2..4 forward / dgrad / wgrad and every nn.Linear GEMM of the update run on the bf16
-                              * MFMA (operands rounded to bf16 when staged, fp32 accumulation); storage, the fused
+                              * conv2..4 forward / dgrad / wgrad and the nn.Linear GEMMs of the update run on the bf16
+                              * MFMA (operands rounded to bf16 when staged, fp32 accumulation) -- except two products of
+                              * the trunk layer that are bound by memory, not arithmetic, and keep their faster fp32
+                              * kernels: its input gradient (always) and its weight gradient below batch 512; storage, the fused
                               * aug + conv1, conv1's weight gradient, LayerNorm, the output heads, losses, Adam and
                               * Polyak stay fp32.  act() always runs in fp32. */
   void* const* timing_events; /* optional (may be NULL): host array of 4 hipEvent_t created with timing enabled.
