@@ -237,3 +237,46 @@ def test_shard_bounds():
     assert shard_bounds(256, 8, 3, False) == (768, 1024, 2048)
     with pytest.raises(ValueError):
         shard_bounds(10, 4, 0, True)
+
+
+def test_bench_self_launch_starts_ranks_without_touching_the_gpu(monkeypatch):
+    """`python bench.py --gpus N` without a launcher: the parent starts N child ranks with the torch.distributed
+    environment (127.0.0.1 rendezvous), relays rank 0's line, returns the first non-zero exit code -- and has not
+    initialised the GPU itself (no torch.cuda call is reachable before the hand-off: torch is imported later)."""
+    import importlib
+    import sys
+    bench = importlib.import_module("bench")
+    started = []
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, stdout=None):
+            started.append((cmd, env, stdout))
+            self.returncode = 0 if env["RANK"] != "1" else 3
+
+        def communicate(self):
+            return (b'{"metric": "x"}\n', None)
+
+        def wait(self):
+            return self.returncode
+
+    monkeypatch.setattr(bench.subprocess, "Popen", FakeProc)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    args = bench.parse_args(["--gpus", "4", "--steps", "3"])
+    rc = bench.launch_ranks(args)
+    assert rc == 3 and len(started) == 4
+    ports = set()
+    for r, (cmd, env, out) in enumerate(started):
+        assert cmd[0] == sys.executable and cmd[1].endswith("bench.py") and cmd[2:] == ["--gpus", "4", "--steps", "3"]
+        assert (env["RANK"], env["LOCAL_RANK"], env["WORLD_SIZE"]) == (str(r), str(r), "4")
+        assert env["MASTER_ADDR"] == "127.0.0.1" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+        ports.add(env["MASTER_PORT"])
+        assert (out == bench.subprocess.PIPE) == (r == 0)
+    assert len(ports) == 1
+    # the module itself imports without torch.cuda work: torch is imported inside main(), after the hand-off
+    src = open(bench.__file__).read()
+    assert src.index("return launch_ranks(args)") < src.index("import torch\n\n    world = int(")
+    # workload defaults: config 2 on one GPU, config 4 (humanoid, ONE global batch of 256) on several
+    assert bench.TASKS["humanoid_run"][:2] == (21, 100) and bench.TASKS["cheetah_run"][:2] == (6, 50)
+    a1, a8 = bench.parse_args([]), bench.parse_args(["--gpus", "8"])
+    assert a1.workload == a8.workload == "auto" and a8.batch == 256 and not a8.weak and a8.exchange == "auto"
