@@ -450,6 +450,9 @@ int drq_trunk_fwd_partial(int nbatch, const float* const* A, long lda, const flo
   const int rows = tm2 ? M / 64 : M / 32;
   int blocks_k = (cus + nbatch * rows - 1) / (nbatch * rows);
   if (blocks_k * 4 > steps) blocks_k = steps / 4;
+  // small batches (one or two row tiles): the consumer (LayerNorm) sums the split-K records row by row, and beyond
+  // ~64 records per element that sum costs more than the extra workgroups save here
+  if (blocks_k > 64) blocks_k = 64;
   if (dbg) {
     const int d = atoi(dbg);
     if (d & 1) g.a_bytes = g.b_bytes = 0;               // every load out of range: MFMA time only
