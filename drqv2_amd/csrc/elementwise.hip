@@ -939,7 +939,7 @@ constexpr int kPolMaxA = 32;
 // global stream in the row loop is p2, 16 rows of it in flight per thread.
 template <int AMAX>    // action_dim rounded up to 8 / 16 / 32: the per-output loops are unrolled over it
 __global__ __launch_bounds__(1024) void policy_out_bwd_kernel(PolBwdArgs a) {
-  extern __shared__ float dpre[];           // [B][A], then 16 x 64 floats of reduction scratch
+  extern __shared__ float dpre[];           // [B][A], then 4 x 16 x 64 floats of reduction scratch
   float* sm = dpre + a.B * a.A;
   const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + c;
@@ -988,19 +988,21 @@ __global__ __launch_bounds__(1024) void policy_out_bwd_kernel(PolBwdArgs a) {
       }
     }
   }
-  // dW3: the 16 row groups of a column are summed in order through LDS, one output row at a time
-  for (int j = 0; j < a.A; ++j) {
-    float v = 0.f;
+  // dW3: the 16 row groups of a column are summed in order through LDS, FOUR output rows per barrier pair (one at a
+  // time cost two workgroup barriers per action dimension: 21 rounds for humanoid_run)
+  for (int j0 = 0; j0 < a.A; j0 += 4) {
 #pragma unroll
     for (int q = 0; q < AMAX; ++q)
-      if (q == j) v = acc[q];
-    sm[rg * 64 + c] = v;
+      if (q >= j0 && q < j0 + 4 && q < a.A) sm[((q - j0) * 16 + rg) * 64 + c] = acc[q];
     __syncthreads();
-    if (rg == 0 && nok) {
-      float t = 0.f;
+    if (threadIdx.x < 256) {
+      const int jj = threadIdx.x >> 6;                 // c = threadIdx.x & 63 here as well
+      if (j0 + jj < a.A && nok) {
+        float t = 0.f;
 #pragma unroll
-      for (int g = 0; g < 16; ++g) t += sm[g * 64 + c];
-      a.dw[(long)j * a.H + n] = t;
+        for (int g = 0; g < 16; ++g) t += sm[(jj * 16 + g) * 64 + c];
+        a.dw[(long)(j0 + jj) * a.H + n] = t;
+      }
     }
     __syncthreads();
   }
@@ -1266,7 +1268,7 @@ int drq_policy_out_bwd(const float* da1, const float* da2, long ld, int col0, co
       A > kPolMaxA)
     return DRQ_EARG;
   if (part && splitk < 1) return DRQ_EARG;
-  const size_t lds = ((size_t)B * A + 16 * 64) * sizeof(float);
+  const size_t lds = ((size_t)B * A + 4 * 16 * 64) * sizeof(float);
   if (lds > 60 * 1024) return DRQ_EARG;
   PolBwdArgs a{da1, da2, ld, col0, mu, p2, w, dp2, dw, db, B, H, A, part, splitk};
   if (A <= 8) hipLaunchKernelGGL(policy_out_bwd_kernel<8>, dim3((H + 63) / 64), dim3(1024), lds, st, a);

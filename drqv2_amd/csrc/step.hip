@@ -583,7 +583,7 @@ int phase_actor_backward(const Ctx& c) {
   const long BH = (long)B * H;
 
   // output layer backward in one kernel (dpre, dW3, db3, dp2) when dpre fits its LDS
-  const bool fused_head = A <= 32 && ((size_t)B * A + 1024) * 4 <= 60 * 1024;
+  const bool fused_head = A <= 32 && ((size_t)B * A + 4 * 1024) * 4 <= 60 * 1024;
   int sk_da = 1;
   // backward through the critic to the action only (critic weight grads are never used: SURVEY A7(iii))
   {
