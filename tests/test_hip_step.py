@@ -526,7 +526,7 @@ def test_soak_300_updates_finite_and_reproducible():
     assert m1["critic_loss"] >= 0.0 and abs(m1["critic_q1"]) < 1e3
 
 
-def _dp2_worker(rank, world, port, cfg, ret, backend="gloo"):
+def _dp2_worker(rank, world, port, cfg, ret, backend="gloo", exchange="allreduce"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -539,7 +539,7 @@ def _dp2_worker(rank, world, port, cfg, ret, backend="gloo"):
         dist.init_process_group("gloo", rank=rank, world_size=world)  # two ranks can share the one GPU of the box
     try:
         ag = make_agent(cfg)
-        ag.enable_data_parallel(batch_is_global=True, global_metrics=True)
+        ag.enable_data_parallel(batch_is_global=True, global_metrics=True, exchange=exchange)
         ref = make_agent(cfg)                                         # same weights, single-process full batch
         out = {}
         for u in range(2):
@@ -603,14 +603,14 @@ def test_direct_exchange_on_device_tensors_side_stream():
     assert dict(ret) == {0: "ok", 1: "ok"}
 
 
-def _run_two_ranks(backend):
+def _run_two_ranks(backend, exchange="allreduce"):
     import socket
     import torch.multiprocessing as mp
     cfg = dict(CASES["small_h64_b6"]); cfg["B"] = 8
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_dp2_worker, args=(2, port, cfg, ret, backend), nprocs=2, join=True)
+    mp.spawn(_dp2_worker, args=(2, port, cfg, ret, backend, exchange), nprocs=2, join=True)
     assert sorted(ret.keys()) == [0, 1]
     for rank in (0, 1):
         out = ret[rank]
@@ -631,8 +631,17 @@ def test_two_rank_data_parallel_update_equals_full_batch_on_gpu():
     _run_two_ranks("gloo")
 
 
+@pytest.mark.parametrize("exchange", ["direct", "auto"])
+def test_two_rank_update_with_direct_exchange(exchange):
+    """The same equivalence with the gradient buckets summed by GradExchange's all-to-all / rank-order sum /
+    all-gather on a side stream ("direct"), and with the mode picked by measurement ("auto": what bench.py uses):
+    the whole overlapped schedule (deferred Adam steps waiting on side-stream handles) on the real kernels."""
+    _run_two_ranks("gloo", exchange)
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI)")
-def test_two_rank_rccl_update_equals_full_batch():
+@pytest.mark.parametrize("exchange", ["allreduce", "direct"])
+def test_two_rank_rccl_update_equals_full_batch(exchange):
     """The same equivalence with one GPU per rank and the gradient exchanges over RCCL (backend nccl): the path
     bench.py --gpus N takes.  Runs wherever the box shows two or more GPUs."""
-    _run_two_ranks("nccl")
+    _run_two_ranks("nccl", exchange)
