@@ -301,7 +301,11 @@ class StepEngine:
         self.rank = dist.get_rank(self.pg)
         self.exchange = GradExchange(self.pg, self.world, self.device, exchange)
         if exchange == "auto" and self.world > 1:
-            self.exchange.calibrate([e - b for b, e in grad_buckets_overlap(self.layout)])
+            try:
+                self.exchange.calibrate([e - b for b, e in grad_buckets_overlap(self.layout)])
+            except RuntimeError as err:          # a backend without all-to-all: every bucket takes the all-reduce
+                self.exchange.choice = {}
+                self.exchange.timings_us = {"error": str(err)[:200]}
 
     def _allreduce_async(self, t):
         """SUM over the ranks that starts once the work queued so far has produced `t` and runs beside what is
