@@ -1111,14 +1111,26 @@ int drq_ln_tanh_bwd_part(const float* dh0, int ld0, const float* dh1, int ld1, c
                          const float* xhat, const float* rstd, const float* gamma, float* dz, float* dln,
                          float* dgamma, float* dbeta, int rows, int F, const float* part, int splitk, int nprob,
                          int ldp, hipStream_t st) {
-  if ((!dh0 && !part) || !h || !xhat || !rstd || !gamma || !dz || !dln || !dgamma || !dbeta || rows <= 0 || F <= 0 ||
+  // dgamma == dbeta == nullptr: the caller computes the parameter gradients elsewhere (from dln and xhat: the rider
+  // workgroup of the trunk weight-gradient launch, or drq_ln_param_grad)
+  if ((!dh0 && !part) || !h || !xhat || !rstd || !gamma || !dz || !dln || (!dgamma != !dbeta) || rows <= 0 || F <= 0 ||
       F > 256)
     return DRQ_EARG;
   if (part && (splitk < 1 || nprob < 1 || nprob > 2 || ldp < F)) return DRQ_EARG;
   LnBwdArgs a{dh0, dh1, h, xhat, rstd, gamma, dz, dln, ld0, ld1, ldh, rows, F, part, splitk, nprob, ldp};
   hipLaunchKernelGGL(ln_tanh_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, a);
   DRQ_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ln_param_grad_kernel, dim3(F), dim3(256), 0, st, (const float*)dln, xhat, dgamma, dbeta, rows, F);
+  if (dgamma) {
+    hipLaunchKernelGGL(ln_param_grad_kernel, dim3(F), dim3(256), 0, st, (const float*)dln, xhat, dgamma, dbeta, rows, F);
+    DRQ_LAUNCH_CHECK();
+  }
+  return DRQ_OK;
+}
+
+// internal (step.hip): the parameter gradients alone
+int drq_ln_param_grad(const float* dln, const float* xhat, float* dgamma, float* dbeta, int rows, int F, hipStream_t st) {
+  if (!dln || !xhat || !dgamma || !dbeta || rows <= 0 || F <= 0 || F > 256) return DRQ_EARG;
+  hipLaunchKernelGGL(ln_param_grad_kernel, dim3(F), dim3(256), 0, st, dln, xhat, dgamma, dbeta, rows, F);
   DRQ_LAUNCH_CHECK();
   return DRQ_OK;
 }

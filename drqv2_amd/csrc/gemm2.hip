@@ -327,17 +327,65 @@ struct TWArgs {
   long lda, ldb, ldc;
   int M, N, K;
   unsigned a_bytes, b_bytes;
+  // rider (optional, ln_rows > 0): ONE extra workgroup computes the LayerNorm parameter gradients of the same trunk
+  // (dgamma[f] = sum_r dln[r][f] xhat[r][f], dbeta[f] = sum_r dln[r][f]) beside the weight-gradient workgroups -- they
+  // only need what the LayerNorm backward just wrote, and as a launch of their own they cost ~5 us of a serial stream
+  const float* ln_dln;
+  const float* ln_xhat;
+  float* ln_dgamma;
+  float* ln_dbeta;
+  int ln_rows, ln_F;
 };
+
+__device__ __forceinline__ void ln_param_rider(const TWArgs& g) {
+  __shared__ float sg[4][64], sb[4][64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int rows = g.ln_rows, F = g.ln_F;
+  for (int f0 = 0; f0 < F; f0 += 64) {
+    const int f = f0 + lane;
+    const bool ok = f < F;
+    const int fc = ok ? f : F - 1;
+    float gs = 0.f, bs = 0.f;
+    for (int r0 = wid; r0 < rows; r0 += 4 * 16) {       // 16 rows in flight per thread, then a fixed-order sum
+      float d[16], x[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int rr = min(r0 + 4 * u, rows - 1);
+        d[u] = g.ln_dln[(long)rr * F + fc];
+        x[u] = g.ln_xhat[(long)rr * F + fc];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (r0 + 4 * u < rows) {
+          gs += d[u] * x[u];
+          bs += d[u];
+        }
+    }
+    sg[wid][lane] = gs;
+    sb[wid][lane] = bs;
+    __syncthreads();
+    if (wid == 0 && ok) {
+      g.ln_dgamma[f] = ((sg[0][lane] + sg[1][lane]) + sg[2][lane]) + sg[3][lane];
+      g.ln_dbeta[f] = ((sb[0][lane] + sb[1][lane]) + sb[2][lane]) + sb[3][lane];
+    }
+    __syncthreads();
+  }
+}
 
 template <int KSTEPS>
 __global__ __launch_bounds__(256, 1) void trunk_wgrad_kernel(TWArgs g) {
   constexpr int NS = 4, D = 3;               // register stages, prefetch distance (k-steps)
   static_assert(KSTEPS % NS == 0, "stage index must be a compile-time constant");
+  const int nblk = (int)gridDim.x - (g.ln_rows > 0 ? 1 : 0);     // the last workgroup is the rider's
+  if (g.ln_rows > 0 && (int)blockIdx.x == nblk) {
+    ln_param_rider(g);
+    return;
+  }
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col = lane & 31, half = lane >> 5;
   const int mtiles = (g.M + 31) >> 5, ntiles = g.N >> 5;
-  const int gw = (int)blockIdx.x * 4 + wid, nw = (int)gridDim.x * 4;
+  const int gw = (int)blockIdx.x * 4 + wid, nw = nblk * 4;
   const int mt = gw % mtiles, grp = gw / mtiles, ngrp = nw / mtiles;
   if (grp >= ngrp) return;
   const int per = ntiles / ngrp, rem = ntiles - per * ngrp;
@@ -407,17 +455,26 @@ __global__ __launch_bounds__(256, 1) void trunk_wgrad_kernel(TWArgs g) {
 
 // internal (gemm.hip): dW [M][ldc] = A^T B with A = dz [K][lda], B = feat [K][ldb], rowsum = column sums of A.
 // Returns DRQ_EARG when the problem is not eligible (the caller then uses the LDS-tiled kernel).
-int drq_trunk_wgrad(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K,
-                    float* rowsum, hipStream_t st) {
+// ln_*: optional rider (see TWArgs): LayerNorm parameter gradients from dln / xhat [ln_rows][ln_F]; ln_rows = 0: none.
+int drq_trunk_wgrad_ln(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K,
+                       float* rowsum, const float* ln_dln, const float* ln_xhat, float* ln_dgamma, float* ln_dbeta,
+                       int ln_rows, int ln_F, hipStream_t st) {
   if (M < 1 || M > 128 || N < 4096 || N % 32 || (K != 128 && K != 256)) return DRQ_EARG;
+  if (ln_rows > 0 && (!ln_dln || !ln_xhat || !ln_dgamma || !ln_dbeta || ln_F < 1 || ln_F > 256)) return DRQ_EARG;
   const size_t ab = (size_t)K * lda * 4, bb = (size_t)K * ldb * 4;
   if (ab >= (1ull << 31) || bb >= (1ull << 31)) return DRQ_EARG;
-  TWArgs g{A, B, C, rowsum, lda, ldb, ldc, M, N, K, (unsigned)ab, (unsigned)bb};
-  const int blocks = drq_num_cus();          // one wave per SIMD (128 + 64 operand registers per lane)
+  TWArgs g{A, B, C, rowsum, lda, ldb, ldc, M, N, K, (unsigned)ab, (unsigned)bb,
+           ln_dln, ln_xhat, ln_dgamma, ln_dbeta, ln_rows > 0 ? ln_rows : 0, ln_F};
+  const int blocks = drq_num_cus() + (ln_rows > 0 ? 1 : 0);   // one wave per SIMD (128 + 64 operand registers per lane)
   if (K == 256) hipLaunchKernelGGL((trunk_wgrad_kernel<8>), dim3(blocks), dim3(256), 0, st, g);
   else hipLaunchKernelGGL((trunk_wgrad_kernel<4>), dim3(blocks), dim3(256), 0, st, g);
   DRQ_LAUNCH_CHECK();
   return DRQ_OK;
+}
+
+int drq_trunk_wgrad(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K,
+                    float* rowsum, hipStream_t st) {
+  return drq_trunk_wgrad_ln(A, lda, B, ldb, C, ldc, M, N, K, rowsum, nullptr, nullptr, nullptr, nullptr, 0, 0, st);
 }
 
 // internal (gemm.hip): split-K partials [nbatch * (*splitk_out)][M][N] of A[b] B[b]^T for the trunk shape.

@@ -44,6 +44,12 @@ int drq_gemm_batched_any(int bf16, int nbatch, const float* const* A, long lda, 
 int drq_gemm_batched_partial_any(int bf16, int nbatch, const float* const* A, long lda, int a_kc, const float* const* B,
                                  long ldb, int b_kc, float* const* C, long ldc, int M, int N, int K,
                                  const float* const* bias, float* ws, size_t ws_bytes, int* splitk_out, hipStream_t st);
+// gemm2.hip (internal): the trunk weight gradient with the LayerNorm parameter gradients riding in the same launch
+int drq_trunk_wgrad_ln(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K,
+                       float* rowsum, const float* ln_dln, const float* ln_xhat, float* ln_dgamma, float* ln_dbeta,
+                       int ln_rows, int ln_F, hipStream_t st);
+extern "C" int drq_ln_param_grad(const float* dln, const float* xhat, float* dgamma, float* dbeta, int rows, int F,
+                                 hipStream_t st);
 // gemm2.hip (internal): weight gradient + input gradient of one hidden layer in one launch
 int drq_gemm2_wgrad_dgrad(int nbatch, const float* const* dy, long lddy, const float* const* x, long ldx,
                           float* const* dw, float* const* db, const float* const* w, long ldw, float* const* dx,
@@ -245,6 +251,23 @@ struct Ctx {
     const int prec = (bf16() && N <= 128 && K >= 4096 && Brows < 512) ? 0 : bf16();
     return drq_gemm_batched_any(prec, n, dy, lddy, 0, x, ldx, 0, dw, K, N, K, Brows, nullptr, 0, nullptr, 0, db, 0, 0, 0,
                                 gemm_ws(), gemm_ws_bytes(), st);
+  }
+  // The trunk's weight gradient dW = dz^T feat (+ bias gradient) with the LayerNorm parameter gradients of the same
+  // trunk riding in the launch (one extra workgroup) when the dedicated kernel takes the shape; `ride` says whether
+  // the LayerNorm backward left them out (ln_rides()).
+  bool ln_rides() const { return !bf16() && s->F <= 128 && (s->B == 128 || s->B == 256); }
+  int trunk_wgrad(const float* dz, const float* feat, float* gw, float* gb, bool ride, const float* dln,
+                  const float* xhat, float* dgamma, float* dbeta) const {
+    const int B = s->B, F = s->F;
+    if (ride) {
+      const int rc = drq_trunk_wgrad_ln(dz, F, feat, R, gw, R, F, (int)R, B, gb, dln, xhat, dgamma, dbeta, B, F, st);
+      if (rc != DRQ_EARG) return rc;
+      const int rc2 = drq_ln_param_grad(dln, xhat, dgamma, dbeta, B, F, st);
+      if (rc2 != 0) return rc2;
+    }
+    const float *dzp[1] = {dz}, *xp[1] = {feat};
+    float *gwp[1] = {gw}, *gbp[1] = {gb};
+    return wgrad(1, dzp, F, xp, R, gwp, gbp, B, F, (int)R);
   }
   // both gradients of one layer (they read the same dy and are independent): one launch when the shape allows
   int wgrad_dgrad(int n, const float* const* dy, long lddy, const float* const* x, long ldx, float* const* dw,
@@ -454,13 +477,15 @@ int phase_critic_heads(const Ctx& c) {
                                 &sk_dha, st));
   }
   // trunk: LayerNorm+tanh backward, then Linear(R -> F)
+  const bool ride = c.ln_rides();
   CK(drq_ln_tanh_bwd_part(c.ws(W_DHA), FA, c.ws(W_DHA) + (long)B * FA, FA, c.ws(W_HA_C), FA, c.ws(W_XHAT_C),
-                          c.ws(W_RSTD_C), c.p(cr.ln_g), c.ws(W_DZ_C), c.ws(W_DLN), c.g(cr.ln_g), c.g(cr.ln_b), B, F,
-                          sk_dha > 1 ? c.gemm_ws() : nullptr, sk_dha, 2, FA, st));
+                          c.ws(W_RSTD_C), c.p(cr.ln_g), c.ws(W_DZ_C), c.ws(W_DLN), ride ? nullptr : c.g(cr.ln_g),
+                          ride ? nullptr : c.g(cr.ln_b), B, F, sk_dha > 1 ? c.gemm_ws() : nullptr, sk_dha, 2, FA, st));
   {
-    const float *dz[1] = {c.ws(W_DZ_C)}, *x[1] = {feat_obs}, *w[1] = {c.p(cr.trunk_w)}, *mk[1] = {feat_obs};
-    float *gw[1] = {c.g(cr.trunk_w)}, *gb[1] = {c.g(cr.trunk_b)}, *dy4[1] = {c.ws(W_DY4)};
-    CK(c.wgrad(1, dz, F, x, R, gw, gb, B, F, (int)R));
+    const float *dz[1] = {c.ws(W_DZ_C)}, *w[1] = {c.p(cr.trunk_w)}, *mk[1] = {feat_obs};
+    float* dy4[1] = {c.ws(W_DY4)};
+    CK(c.trunk_wgrad(c.ws(W_DZ_C), feat_obs, c.g(cr.trunk_w), c.g(cr.trunk_b), ride, c.ws(W_DLN), c.ws(W_XHAT_C),
+                     c.g(cr.ln_g), c.g(cr.ln_b)));
     // d feat = dz W_t, masked by relu(conv4) and scattered into the padded conv-gradient layout
     // (fp32 in both precisions: this product is bound by its 8 bytes per output element, not by arithmetic, and the
     // dedicated kernel moves them faster than the tiled bf16 GEMM: 29 vs 49 us at B=256, 317 vs 371 us at B=2048)
@@ -628,14 +653,12 @@ int phase_actor_backward(const Ctx& c) {
     CK(drq_gemm_batched_partial_any(c.bf16(), 1, dp1c, H, 1, w0, F, 0, dh, F, B, F, H, nullptr, c.gemm_ws(), c.gemm_ws_bytes(), &sk_dh,
                                 st));
   }
+  const bool ride = c.ln_rides();
   CK(drq_ln_tanh_bwd_part(c.ws(W_DH_A), F, nullptr, 0, c.ws(W_HROWS), F, c.ws(W_XHAT_A), c.ws(W_RSTD_A), c.p(ac.ln_g),
-                          c.ws(W_DZ_A), c.ws(W_DLN), c.g(ac.ln_g), c.g(ac.ln_b), B, F,
+                          c.ws(W_DZ_A), c.ws(W_DLN), ride ? nullptr : c.g(ac.ln_g), ride ? nullptr : c.g(ac.ln_b), B, F,
                           sk_dh > 1 ? c.gemm_ws() : nullptr, sk_dh, 1, F, st));
-  {
-    const float *dz[1] = {c.ws(W_DZ_A)}, *x[1] = {feat_obs};
-    float *gw[1] = {c.g(ac.trunk_w)}, *gb[1] = {c.g(ac.trunk_b)};
-    CK(c.wgrad(1, dz, F, x, R, gw, gb, B, F, (int)R));
-  }
+  CK(c.trunk_wgrad(c.ws(W_DZ_A), feat_obs, c.g(ac.trunk_w), c.g(ac.trunk_b), ride, c.ws(W_DLN), c.ws(W_XHAT_A),
+                   c.g(ac.ln_g), c.g(ac.ln_b)));
   return 0;
 }
 
