@@ -62,6 +62,14 @@ struct Conv1AugArgs {
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_c1 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_c1 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack_bf16_c1(float lo, float hi) {      // RNE, lo in bits 15:0
+  typedef __bf16 bf16x2_c1 __attribute__((ext_vector_type(2)));
+  const bf16x2_c1 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, v);
+}
 
 __device__ __forceinline__ float div255(float v) {   // correctly rounded v / 255 (see elementwise.hip)
   const float r = 1.0f / 255.0f;
@@ -72,7 +80,12 @@ __device__ __forceinline__ float div255(float v) {   // correctly rounded v / 25
 
 // ABL (development build only, tools/conv1aug_ab.py): timing ablations -- 1 skips stage 3 (tiles), 2 skips stage 2
 // (augmentation), 4 skips the stage-2 global stores, 8 skips the LDS-DMA of the source rows
-template <int ABL>
+// BF (the bf16 update path, DrqStep.bf16): stage 3 runs on v_mfma_f32_32x32x16_bf16 -- one MFMA per tap with k = 16
+// channel slots (9 real channels; lanes 0-31 supply channels 0-7, lanes 32-63 channel 8 and seven zero weights), the
+// operands rounded to bf16 as they are read from the fp32 LDS tile.  Stages 1 and 2 (and the stored encoder input)
+// are unchanged.  The bf16 matrix unit is separate from the f32 VALU datapath: here the two workgroups of a CU DO
+// overlap (one augments while the other multiplies).
+template <int ABL, bool BF = false>
 __global__ __launch_bounds__(NTHR, 2 * NTHR / 256) void conv1_aug_kernel(Conv1AugArgs a) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -115,6 +128,22 @@ __global__ __launch_bounds__(NTHR, 2 * NTHR / 256) void conv1_aug_kernel(Conv1Au
       const int cin = 2 * c + half;
       wreg[c * 9 + t] = cin < C ? a.w[(col * C + cin) * 9 + t] : 0.f;
     }
+  // BF: fragment t (tap) holds w[cout = col][channel 8*half + j][t], j = 0..7 (channels >= 9: zero)
+  bf16x8_c1 wfb[9];
+  if constexpr (BF) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float wv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int cin = 8 * half + j;
+        wv[j] = cin < C ? a.w[(col * C + (cin < C ? cin : 0)) * 9 + t] : 0.f;
+      }
+      const u32x4_c1 pk = {pack_bf16_c1(wv[0], wv[1]), pack_bf16_c1(wv[2], wv[3]), pack_bf16_c1(wv[4], wv[5]),
+                           pack_bf16_c1(wv[6], wv[7])};
+      wfb[t] = __builtin_bit_cast(bf16x8_c1, pk);
+    }
+  }
   float breg[16];     // accumulator row (cout) of register r: (r&3) + 8*(r>>2) + 4*half
 #pragma unroll
   for (int r = 0; r < 16; ++r) breg[r] = a.bias[(r & 3) + 8 * (r >> 2) + 4 * half];
@@ -313,11 +342,28 @@ __global__ __launch_bounds__(NTHR, 2 * NTHR / 256) void conv1_aug_kernel(Conv1Au
       const int p = p0 < npix ? p0 : npix - 1;
       const int oyl = p / HO, ox = p - oyl * HO;
       const float* xb = xs + (2 * oyl) * XPITCH + ox;
-      float X[2][9];
-      load_group(X[0], xb, 0);
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = breg[r];
+      if constexpr (BF) {
+        // slot j of this lane: channel 8*half + j; the zero-weight slots of the upper half re-read channel 8
+        const float* xj[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xj[j] = xb + (half ? C - 1 : j) * (NROWS * XPITCH);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int ky = t / 3, kx = t - 3 * ky;
+          const int off = ky * XPITCH + (kx == 1 ? XPL : 0) + (kx == 2 ? 1 : 0);
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = xj[j][off];
+          const u32x4_c1 pk = {pack_bf16_c1(v[0], v[1]), pack_bf16_c1(v[2], v[3]), pack_bf16_c1(v[4], v[5]),
+                               pack_bf16_c1(v[6], v[7])};
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfb[t], __builtin_bit_cast(bf16x8_c1, pk), acc, 0, 0, 0);
+        }
+      } else {
+      float X[2][9];
+      load_group(X[0], xb, 0);
 #pragma unroll
       for (int c = 0; c < CP; ++c) {
         // the next pair's reads go out right behind this pair's first MFMA: they are then the youngest LDS
@@ -330,6 +376,7 @@ __global__ __launch_bounds__(NTHR, 2 * NTHR / 256) void conv1_aug_kernel(Conv1Au
         for (int t = 1; t < 9; ++t)
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[c * 9 + t], X[c & 1][t], acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+      }
       }
       const int oy = done.r0 + oyl;
       const int yoff = p0 < npix ? (((done.f * 32 + 4 * half) * HO + oy) * HO + ox) * 4 : (int)0x80000000u;
@@ -358,9 +405,10 @@ extern "C" DRQ_API void drq_dev_conv1aug_stamps(void* p) { g_conv1aug_stamps = (
 
 // C ABI (include/drqv2_hip.h): both views of the update through aug + conv1 in one launch.
 //   y [2n][32][41][41] = relu(conv1(aug(view)/255 - 0.5));  xaug [2n][9][84][84]: frames [0, n_store) are written.
-extern "C" DRQ_API int drq_conv1_aug_fwd(const uint8_t* obs, const float* shift, const uint8_t* obs1, const float* shift1,
-                      const float* base_grid, const float* w, const float* bias, float* xaug, float* y, int n,
-                      int n_store, hipStream_t st) {
+// bf_mma != 0: the layer's products on the bf16 MFMA (the bf16 update path; internal and drq_conv1_aug_fwd_bf16)
+int drq_conv1_aug_fwd_any(int bf_mma, const uint8_t* obs, const float* shift, const uint8_t* obs1, const float* shift1,
+                          const float* base_grid, const float* w, const float* bias, float* xaug, float* y, int n,
+                          int n_store, hipStream_t st) {
   if (!obs || !shift || !obs1 || !shift1 || !base_grid || !w || !bias || !y || n <= 0 || n_store < 0 || n_store > 2 * n)
     return DRQ_EARG;
   if (n_store > 0 && !xaug) return DRQ_EARG;
@@ -377,6 +425,8 @@ extern "C" DRQ_API int drq_conv1_aug_fwd(const uint8_t* obs, const float* shift,
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv1_aug_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        LDS_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)conv1_aug_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
 #ifdef DRQ_DEV
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv1_aug_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv1_aug_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -403,6 +453,11 @@ extern "C" DRQ_API int drq_conv1_aug_fwd(const uint8_t* obs, const float* shift,
       said = true;
     }
   }
+  if (bf_mma) {
+    hipLaunchKernelGGL((conv1_aug_kernel<0, true>), dim3((unsigned)blocks), dim3(NTHR), LDS_BYTES, st, a);
+    DRQ_LAUNCH_CHECK();
+    return DRQ_OK;
+  }
   switch (g_conv1aug_variant) {
     case 1: hipLaunchKernelGGL(conv1_aug_kernel<1>, dim3((unsigned)blocks), dim3(NTHR), LDS_BYTES, st, a); break;
     case 2: hipLaunchKernelGGL(conv1_aug_kernel<2>, dim3((unsigned)blocks), dim3(NTHR), LDS_BYTES, st, a); break;
@@ -412,8 +467,25 @@ extern "C" DRQ_API int drq_conv1_aug_fwd(const uint8_t* obs, const float* shift,
     default: hipLaunchKernelGGL(conv1_aug_kernel<0>, dim3((unsigned)blocks), dim3(NTHR), LDS_BYTES, st, a);
   }
 #else
-  hipLaunchKernelGGL(conv1_aug_kernel<0>, dim3((unsigned)blocks), dim3(NTHR), LDS_BYTES, st, a);
+  if (bf_mma) hipLaunchKernelGGL((conv1_aug_kernel<0, true>), dim3((unsigned)blocks), dim3(NTHR), LDS_BYTES, st, a);
+  else hipLaunchKernelGGL(conv1_aug_kernel<0>, dim3((unsigned)blocks), dim3(NTHR), LDS_BYTES, st, a);
 #endif
   DRQ_LAUNCH_CHECK();
   return DRQ_OK;
 }
+
+extern "C" {
+
+DRQ_API int drq_conv1_aug_fwd(const uint8_t* obs, const float* shift, const uint8_t* obs1, const float* shift1,
+                              const float* base_grid, const float* w, const float* bias, float* xaug, float* y, int n,
+                              int n_store, hipStream_t st) {
+  return drq_conv1_aug_fwd_any(0, obs, shift, obs1, shift1, base_grid, w, bias, xaug, y, n, n_store, st);
+}
+
+DRQ_API int drq_conv1_aug_fwd_bf16(const uint8_t* obs, const float* shift, const uint8_t* obs1, const float* shift1,
+                                   const float* base_grid, const float* w, const float* bias, float* xaug, float* y,
+                                   int n, int n_store, hipStream_t st) {
+  return drq_conv1_aug_fwd_any(1, obs, shift, obs1, shift1, base_grid, w, bias, xaug, y, n, n_store, st);
+}
+
+}  // extern "C"

@@ -44,6 +44,10 @@ int drq_gemm_batched_any(int bf16, int nbatch, const float* const* A, long lda, 
 int drq_gemm_batched_partial_any(int bf16, int nbatch, const float* const* A, long lda, int a_kc, const float* const* B,
                                  long ldb, int b_kc, float* const* C, long ldc, int M, int N, int K,
                                  const float* const* bias, float* ws, size_t ws_bytes, int* splitk_out, hipStream_t st);
+// conv1aug.hip (internal): bf_mma selects the bf16-MFMA form of the layer's products
+int drq_conv1_aug_fwd_any(int bf_mma, const uint8_t* obs, const float* shift, const uint8_t* obs1, const float* shift1,
+                          const float* base_grid, const float* w, const float* bias, float* xaug, float* y, int n,
+                          int n_store, hipStream_t st);
 // gemm2.hip (internal): the trunk weight gradient with the LayerNorm parameter gradients riding in the same launch
 int drq_trunk_wgrad_ln(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K,
                        float* rowsum, const float* ln_dln, const float* ln_xhat, float* ln_dgamma, float* ln_dbeta,
@@ -373,8 +377,8 @@ int phase_encode(const Ctx& c) {
   // aug (drqv2.py:241-242) + /255-0.5 (:64) + conv1 (:55) in one kernel that reads the uint8 frames once; rows
   // [0,B) = obs, [B,2B) = next_obs.  Only the obs view's encoder input is kept (conv1's weight gradient reads it).
   (void)C;
-  CK(drq_conv1_aug_fwd(s->obs, s->shift_obs, s->next_obs, s->shift_next, s->base_grid, c.p(c.P.enc_w[0]),
-                       c.p(c.P.enc_b[0]), aug, c.ws(W_ACT1), B, s->store_aug_next ? 2 * B : B, st));
+  CK(drq_conv1_aug_fwd_any(c.bf16(), s->obs, s->shift_obs, s->next_obs, s->shift_next, s->base_grid,
+                           c.p(c.P.enc_w[0]), c.p(c.P.enc_b[0]), aug, c.ws(W_ACT1), B, s->store_aug_next ? 2 * B : B, st));
   // layers 2..4 on both views in one pass (:244-246)
   CK(encoder_forward(c, nullptr, 2 * B, c.ws(W_ACT1), c.ws(W_ACT2), c.ws(W_ACT3), c.ws(W_FEAT), true));
   return 0;

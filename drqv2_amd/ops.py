@@ -52,7 +52,7 @@ def random_shifts_aug(x, shift, pad=4, base=None, fuse_norm=False):
     return out
 
 
-def conv1_aug_fwd(obs, shift, obs1, shift1, w, b, n_store=None, base=None):
+def conv1_aug_fwd(obs, shift, obs1, shift1, w, b, n_store=None, base=None, bf16=False):
     """Fused RandomShiftsAug + /255-0.5 + conv1 + ReLU on both views (drq_conv1_aug_fwd).
     Returns (y [2n,32,41,41], xaug [2n,9,84,84] with frames [0,n_store) written, the rest zero)."""
     lib = _lib.load()
@@ -66,8 +66,9 @@ def conv1_aug_fwd(obs, shift, obs1, shift1, w, b, n_store=None, base=None):
     n_store = n if n_store is None else n_store
     y = torch.empty((2 * n, 32, 41, 41), device=obs.device, dtype=torch.float32)
     xaug = torch.zeros((2 * n, 9, 84, 84), device=obs.device, dtype=torch.float32)
-    check(lib.drq_conv1_aug_fwd(ptr(obs), ptr(shift), ptr(obs1), ptr(shift1), ptr(base), ptr(_need(w, name="w")),
-                                ptr(_need(b, name="b")), ptr(xaug), ptr(y), n, n_store, _stream()), "drq_conv1_aug_fwd")
+    fn = lib.drq_conv1_aug_fwd_bf16 if bf16 else lib.drq_conv1_aug_fwd
+    check(fn(ptr(obs), ptr(shift), ptr(obs1), ptr(shift1), ptr(base), ptr(_need(w, name="w")), ptr(_need(b, name="b")),
+             ptr(xaug), ptr(y), n, n_store, _stream()), "drq_conv1_aug_fwd")
     return y, xaug
 
 

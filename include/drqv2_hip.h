@@ -49,6 +49,11 @@ int drq_aug_fwd_f32(const float* x, const float* shift_xy, const float* base_gri
 int drq_conv1_aug_fwd(const uint8_t* obs, const float* shift, const uint8_t* obs1, const float* shift1,
                       const float* base_grid, const float* w, const float* bias, float* xaug, float* y, int n,
                       int n_store, drq_stream_t stream);
+/* the same with the layer's products on the bf16 MFMA (the bf16 update path, see the bf16 conv entries below): the
+ * augmentation and the stored encoder input are the fp32 ones, bit for bit; y = relu(conv(bf16(x), bf16(w)) + b). */
+int drq_conv1_aug_fwd_bf16(const uint8_t* obs, const float* shift, const uint8_t* obs1, const float* shift1,
+                           const float* base_grid, const float* w, const float* bias, float* xaug, float* y, int n,
+                           int n_store, drq_stream_t stream);
 
 /* ---- Encoder conv layers (drqv2.py:55-59): Conv2d(cin,32,3,stride)+ReLU, 32 output channels.
  * Supported (cin,hin,stride): (9,84,2) (32,41,1) (32,39,1) (32,37,1).  y element (b,co,oy,ox) is
@@ -212,8 +217,9 @@ typedef struct {
                               * conv2..4 forward / dgrad / wgrad and the nn.Linear GEMMs of the update run on the bf16
                               * MFMA (operands rounded to bf16 when staged, fp32 accumulation) -- except two products of
                               * the trunk layer that are bound by memory, not arithmetic, and keep their faster fp32
-                              * kernels: its input gradient (always) and its weight gradient below batch 512; storage, the fused
-                              * aug + conv1, conv1's weight gradient, LayerNorm, the output heads, losses, Adam and
+                              * kernels: its input gradient (always) and its weight gradient below batch 512; conv1 (fused with
+                              * the augmentation) multiplies on the bf16 MFMA too; storage, the augmentation arithmetic,
+                              * conv1's weight gradient, LayerNorm, the output heads, losses, Adam and
                               * Polyak stay fp32.  act() always runs in fp32. */
   void* const* timing_events; /* optional (may be NULL): host array of 4 hipEvent_t created with timing enabled.
                               * Instrumentation for bench.py's roofline: [0],[1] are recorded on `stream` right
