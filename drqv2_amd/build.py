@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdrqv2_hip.so")
 LIB_DEV = os.path.join(HERE, "libdrqv2_hip_dev.so")
-SOURCES = ["conv.hip", "conv1aug.hip", "conv_bf16.hip", "gemm.hip", "gemm2.hip", "skinny.hip", "elementwise.hip", "step.hip"]
+SOURCES = ["conv.hip", "conv_wino.hip", "conv1aug.hip", "conv_bf16.hip", "gemm.hip", "gemm2.hip", "skinny.hip", "elementwise.hip", "step.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-fvisibility=hidden"]
 

@@ -1,0 +1,301 @@
+// 3x3 stride-1 convolution of the encoder's 32->32 layers in Winograd F(2x2,3x3) form on the f32 matrix cores.
+//
+// Reference op: nn.Conv2d(32,32,3,1) + ReLU (drqv2.py:56-58) and its input gradient.  Same interface and data
+// layouts as conv3x3_kernel (conv.hip); the arithmetic is the minimal-filtering form
+//     Y = A^T [ (G g G^T) .* (B^T d B) ] A        (Lavin & Gray), summed over the 32 input channels,
+// i.e. per 2x2 output tile 16 channel-GEMMs of 32x32 instead of 36 tap-GEMMs: 2.25x fewer matrix FLOPs, paid for
+// with 32 adds per (tile, input channel) and 24 adds per (tile, output channel) on the VALU.  All of it fp32; the
+// result differs from the direct form by rounding only (measured 1.9e-7 vs 1.6e-7 normwise against fp64).
+//
+// Mapping: v_mfma_f32_16x16x4_f32, D[cout 16][tile 16] += U[cout][cin 4] * V[cin 4][tile].  A wave owns a "unit" of
+// 16 consecutive tiles of the flattened (sample, tile row, tile column) index and all 32 output channels:
+// 16 positions x 2 cout halves x 4 registers = 128 accumulator registers, two waves per SIMD.  Lane l holds tile
+// l&15 and input channel 4c + (l>>4) of k-step c: it loads that channel's 4x4 input patch (four 16-byte loads),
+// transforms it in registers and feeds the 16 positions.  U = G g G^T is computed once per workgroup into LDS in
+// MFMA-lane order (one ds_read_b64 per position and k-step serves both cout halves).
+#include "common.h"
+
+namespace {
+
+struct WinoArgs {
+  const float* x;      // [NB][32][HIN][HIN]
+  const float* w;      // canonical [32][32][3][3]
+  const float* bias;   // [32] or null
+  const float* mask;   // [NB][32][HOUT][HOUT] or null : out *= (mask > 0)
+  float* y;
+  int y_bs, y_cs, y_rs, y_off;   // output strides (elements)
+  unsigned x_bytes, y_bytes, mask_bytes;
+  int nb;
+  int relu;
+  int wmode;           // 0 forward gather, 1 dgrad gather (transposed + flipped)
+};
+
+typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
+typedef float f32x2w __attribute__((ext_vector_type(2)));
+
+template <int HIN, bool MASK>
+__global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
+#pragma clang fp contract(off)
+  constexpr int HOUT = HIN - 2;
+  constexpr int TH = (HOUT + 1) / 2;         // tiles per dimension (the last one is half empty: HOUT is odd)
+  constexpr int TT = TH * TH;
+  constexpr int PLANE = HIN * HIN * 4;       // bytes of one input channel
+  __shared__ __attribute__((aligned(16))) float U[16 * 8 * 64 * 2];   // [pos][k-step][lane][cout half]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int tl = lane & 15;     // tile of the unit (B column / D column)
+  const int kk = lane >> 4;     // input channel inside the k-step (A/B k index); D rows 4*kk + r
+
+  // ---- U = G g G^T for the 1024 (cout, cin) filters -> LDS
+  for (int q = tid; q < 1024; q += 256) {
+    const int oc = q >> 5, ic = q & 31;      // output channel (A row) / reduction channel of THIS product
+    float g[9];
+    if (a.wmode == 0) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) g[t] = a.w[(oc * 32 + ic) * 9 + t];
+    } else {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) g[t] = a.w[(ic * 32 + oc) * 9 + (8 - t)];
+    }
+    float tm[4][3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const float g0 = g[kx], g1 = g[3 + kx], g2 = g[6 + kx];
+      tm[0][kx] = g0;
+      tm[1][kx] = 0.5f * ((g0 + g2) + g1);
+      tm[2][kx] = 0.5f * ((g0 + g2) - g1);
+      tm[3][kx] = g2;
+    }
+    const int c = ic >> 2, k4 = ic & 3, h = oc >> 4;
+    float* dst = U + ((size_t)c * 64 + k4 * 16 + (oc & 15)) * 2 + h;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float t0 = tm[i][0], t1 = tm[i][1], t2 = tm[i][2];
+      dst[(i * 4 + 0) * (8 * 64 * 2)] = t0;
+      dst[(i * 4 + 1) * (8 * 64 * 2)] = 0.5f * ((t0 + t2) + t1);
+      dst[(i * 4 + 2) * (8 * 64 * 2)] = 0.5f * ((t0 + t2) - t1);
+      dst[(i * 4 + 3) * (8 * 64 * 2)] = t2;
+    }
+  }
+  // bias of this lane's eight output channels: cout = 16*h + 4*kk + r
+  float bv[2][4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[h][r] = a.bias ? a.bias[16 * h + 4 * kk + r] : 0.f;
+  __syncthreads();
+
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, a.y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t mrs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.mask, 0, a.mask ? a.mask_bytes : 0, 0x00020000);
+  constexpr int kDrop = (int)0x80000000u;    // beyond any num_records: the store is discarded
+
+  const int ntile = a.nb * TT;
+  const int nunit = (ntile + 15) >> 4;
+  const int nwave = (int)gridDim.x * 4;
+  const f32x2w* Ul = reinterpret_cast<const f32x2w*>(U) + lane;
+
+  auto patch_voff = [&](int unit) {          // byte offset of this lane's patch (channel kk of k-step 0)
+    int t = unit * 16 + tl;
+    t = t < ntile ? t : ntile - 1;
+    const int b = t / TT, rem = t - b * TT;
+    const int ty = rem / TH, tx = rem - ty * TH;
+    return (((b * 32 + kk) * HIN + 2 * ty) * HIN + 2 * tx) * 4;
+  };
+  auto load_patch = [&](float (&d)[16], int voff, int c) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const u32x4w v = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, c * (4 * PLANE) + i * (HIN * 4), 0);
+      const unsigned e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];
+      d[i * 4 + 0] = __uint_as_float(e0);
+      d[i * 4 + 1] = __uint_as_float(e1);
+      d[i * 4 + 2] = __uint_as_float(e2);
+      d[i * 4 + 3] = __uint_as_float(e3);
+    }
+  };
+
+  // A operands: positions [8*g, 8*g+8) of k-step c -> 16 registers (both cout halves per ds_read_b64)
+  auto load_A = [&](f32x2w (&A)[8], int c, int g) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) A[p] = Ul[((8 * g + p) * 8 + c) * 64];
+  };
+
+  int unit = blockIdx.x * 4 + wid;
+  float d[16];
+  f32x2w A0[8], A1[8];
+  int voff = 0;
+  if (unit < nunit) {
+    voff = patch_voff(unit);
+    load_patch(d, voff, 0);
+    load_A(A0, 0, 0);
+  }
+  for (; unit < nunit; unit += nwave) {
+    const int nvoff = patch_voff(unit + nwave < nunit ? unit + nwave : unit);
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      // Every k-step is pinned into the same issue order (sched_barrier): the patch of the NEXT step and the A
+      // operands of the next half-step are requested a half-step (>= 512 matrix cycles) before they are used.
+      // The memory clobber keeps the loop-invariant LDS reads from being hoisted out of the loops (256 registers).
+      asm volatile("" ::: "memory");
+      float t[16];                           // B^T d
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        t[0 * 4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
+        t[1 * 4 + j] = d[1 * 4 + j] + d[2 * 4 + j];
+        t[2 * 4 + j] = d[2 * 4 + j] - d[1 * 4 + j];
+        t[3 * 4 + j] = d[1 * 4 + j] - d[3 * 4 + j];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 1 < 8) load_patch(d, voff, c + 1);
+      else load_patch(d, nvoff, 0);
+      load_A(A1, c, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      float V[16];                           // (B^T d) B, all of it ahead of the MFMAs (no VALU->MFMA hazard per use)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        V[i * 4 + 0] = t[i * 4 + 0] - t[i * 4 + 2];
+        V[i * 4 + 1] = t[i * 4 + 1] + t[i * 4 + 2];
+        V[i * 4 + 2] = t[i * 4 + 2] - t[i * 4 + 1];
+        V[i * 4 + 3] = t[i * 4 + 1] - t[i * 4 + 3];
+      }
+      auto half_step = [&](const f32x2w (&A)[8], int g) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+          const int pos = 8 * g + p;
+          const f32x2w Ap = A[p];
+          if (c == 0) {
+            // position (1,1) enters all four outputs of the tile with weight +1: the bias rides in its accumulator
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 b0 = {bv[0][0], bv[0][1], bv[0][2], bv[0][3]}, b1 = {bv[1][0], bv[1][1], bv[1][2], bv[1][3]};
+            acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[0], V[pos], pos == 5 ? b0 : z, 0, 0, 0);
+            acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[1], V[pos], pos == 5 ? b1 : z, 0, 0, 0);
+          } else {
+            acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[0], V[pos], acc[pos][0], 0, 0, 0);
+            acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[1], V[pos], acc[pos][1], 0, 0, 0);
+          }
+        }
+      };
+      half_step(A0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_A(A0, (c + 1) & 7, 0);            // the next k-step's (or the next unit's first) lower half
+      __builtin_amdgcn_sched_barrier(0);
+      half_step(A1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- output transform Y = A^T M A, bias, ReLU / mask, stores
+    {
+      const int t0 = unit * 16 + tl;
+      const bool valid = t0 < ntile;
+      const int t = valid ? t0 : ntile - 1;
+      const int b = t / TT, rem = t - b * TT;
+      const int ty = rem / TH, tx = rem - ty * TH;
+      const bool c1ok = 2 * tx + 1 < HOUT, r1ok = 2 * ty + 1 < HOUT;
+      const int ybase = (a.y_off + b * a.y_bs + (4 * kk) * a.y_cs + (2 * ty) * a.y_rs + 2 * tx) * 4;
+      const int mbase = (((b * 32 + 4 * kk) * HOUT + 2 * ty) * HOUT + 2 * tx) * 4;
+      const bool edge = __builtin_amdgcn_ballot_w64(valid && !c1ok) != 0;
+      // the ReLU mask of the layer below: all 16 loads go out before the transform arithmetic
+      u32x2w mk[2][4][2];
+      if constexpr (MASK) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+              mk[h][r][i] = __builtin_amdgcn_raw_buffer_load_b64(mrs, mbase + i * (HOUT * 4),
+                                                                 (16 * h + r) * (HOUT * HOUT * 4), 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float s[2][4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float m0 = acc[0 * 4 + j][h][r], m1 = acc[1 * 4 + j][h][r], m2 = acc[2 * 4 + j][h][r],
+                        m3 = acc[3 * 4 + j][h][r];
+            s[0][j] = (m0 + m1) + m2;
+            s[1][j] = (m1 - m2) - m3;
+          }
+          const int co = (16 * h + r);       // + 4*kk rides in the lane's base offset
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            float y0 = (s[i][0] + s[i][1]) + s[i][2];
+            float y1 = (s[i][1] - s[i][2]) - s[i][3];
+            if (a.relu) {
+              y0 = y0 > 0.f ? y0 : 0.f;
+              y1 = y1 > 0.f ? y1 : 0.f;
+            }
+            if constexpr (MASK) {
+              const unsigned q0 = mk[h][r][i][0], q1 = mk[h][r][i][1];
+              y0 = __uint_as_float(q0) > 0.f ? y0 : 0.f;
+              y1 = __uint_as_float(q1) > 0.f ? y1 : 0.f;
+            }
+            const bool rowok = valid && (i == 0 || r1ok);
+            const int soff = (co * a.y_cs + i * a.y_rs) * 4;       // wave-uniform: scalar offset
+            const u32x2w pk = {__float_as_uint(y0), __float_as_uint(y1)};
+            __builtin_amdgcn_raw_buffer_store_b64(pk, yrs, (rowok && c1ok) ? ybase : kDrop, soff, 0);
+            if (edge) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y0), yrs, (rowok && !c1ok) ? ybase : kDrop, soff, 0);
+          }
+        }
+    }
+    voff = nvoff;
+  }
+}
+
+template <int HIN>
+int launch_wino(const WinoArgs& a, hipStream_t st) {
+  constexpr int HOUT = HIN - 2, TH = (HOUT + 1) / 2;
+  const long nunit = ((long)a.nb * TH * TH + 15) / 16;
+  long blocks = (nunit + 3) / 4;
+  const long cap = 2L * drq_num_cus();
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  if (a.mask) hipLaunchKernelGGL((conv3x3_wino_kernel<HIN, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv3x3_wino_kernel<HIN, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Same contract as drq_conv3x3_fwd (conv.hip) for cin = 32, stride 1, in Winograd form (rounding differs).
+DRQ_API int drq_conv3x3_fwd_wino(const float* x, const float* w, const float* bias, float* y, int nb, int hin, int relu,
+                                 long y_bs, long y_cs, long y_rs, long y_off, hipStream_t st) {
+  if (!x || !w || !y || nb <= 0) return DRQ_EARG;
+  const size_t xb = (size_t)nb * 32 * hin * hin * 4;
+  const size_t yb = (size_t)nb * y_bs * 4;
+  if (xb >= (1ull << 31) || yb >= (1ull << 31) || y_off < 0 || y_bs <= 0) return DRQ_EARG;
+  WinoArgs a{x, w, bias, nullptr, y, (int)y_bs, (int)y_cs, (int)y_rs, (int)y_off, (unsigned)xb, (unsigned)yb, 0u, nb, relu, 0};
+  if (hin == 41) return launch_wino<41>(a, st);
+  if (hin == 39) return launch_wino<39>(a, st);
+  if (hin == 37) return launch_wino<37>(a, st);
+  return DRQ_EARG;
+}
+
+// Same contract as drq_conv3x3_dgrad (conv.hip) in Winograd form.
+DRQ_API int drq_conv3x3_dgrad_wino(const float* dy_pad, const float* w, const float* mask, float* dx, int nb, int hout,
+                                   long dx_bs, long dx_cs, long dx_rs, long dx_off, hipStream_t st) {
+  if (!dy_pad || !w || !dx || nb <= 0) return DRQ_EARG;
+  const int hp = hout + 4;
+  const size_t xb = (size_t)nb * 32 * hp * hp * 4;
+  const size_t yb = (size_t)nb * dx_bs * 4;
+  const size_t mb = (size_t)nb * 32 * (hout + 2) * (hout + 2) * 4;
+  if (xb >= (1ull << 31) || yb >= (1ull << 31) || dx_off < 0 || dx_bs <= 0) return DRQ_EARG;
+  WinoArgs a{dy_pad, w, nullptr, mask, dx, (int)dx_bs, (int)dx_cs, (int)dx_rs, (int)dx_off, (unsigned)xb, (unsigned)yb,
+             (unsigned)mb, nb, 0, 1};
+  if (hp == 39) return launch_wino<39>(a, st);
+  if (hp == 41) return launch_wino<41>(a, st);
+  if (hp == 43) return launch_wino<43>(a, st);
+  return DRQ_EARG;
+}
+
+}  // extern "C"

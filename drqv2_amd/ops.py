@@ -80,12 +80,16 @@ def u8_normalize(x):
     return y
 
 
-def conv3x3_fwd(x, w, b, stride, relu=True, bf16=False):
+def conv3x3_fwd(x, w, b, stride, relu=True, bf16=False, wino=False):
     lib = _lib.load()
     _need(x, name="x"), _need(w, name="w"), _need(b, name="b")
     nb, cin, hin, _ = x.shape
     hout = (hin - 3) // stride + 1
     y = torch.empty((nb, 32, hout, hout), device=x.device, dtype=torch.float32)
+    if wino:
+        check(lib.drq_conv3x3_fwd_wino(ptr(x), ptr(w), ptr(b), ptr(y), nb, hin, int(relu), 32 * hout * hout, hout * hout,
+                                       hout, 0, _stream()), "drq_conv3x3_fwd_wino")
+        return y
     if bf16:
         check(lib.drq_conv3x3_fwd_bf16(ptr(x), ptr(w), ptr(b), ptr(y), nb, hin, int(relu), 32 * hout * hout, hout * hout,
                                        hout, 0, _stream()), "drq_conv3x3_fwd_bf16")
@@ -95,7 +99,7 @@ def conv3x3_fwd(x, w, b, stride, relu=True, bf16=False):
     return y
 
 
-def conv3x3_dgrad(dy_pad, w, mask, bf16=False):
+def conv3x3_dgrad(dy_pad, w, mask, bf16=False, wino=False):
     """dy_pad [nb,32,hout+4,hout+4] (zero border of 2) -> dx [nb,32,hout+2,hout+2] * (mask>0)."""
     lib = _lib.load()
     _need(dy_pad, name="dy_pad"), _need(w, name="w")
@@ -106,6 +110,10 @@ def conv3x3_dgrad(dy_pad, w, mask, bf16=False):
         _need(mask, name="mask")
         assert tuple(mask.shape) == (nb, 32, hin, hin)
     dx = torch.empty((nb, 32, hin, hin), device=dy_pad.device, dtype=torch.float32)
+    if wino:
+        check(lib.drq_conv3x3_dgrad_wino(ptr(dy_pad), ptr(w), ptr(mask), ptr(dx), nb, hout, 32 * hin * hin, hin * hin, hin,
+                                         0, _stream()), "drq_conv3x3_dgrad_wino")
+        return dx
     if bf16:
         check(lib.drq_conv3x3_dgrad_bf16(ptr(dy_pad), ptr(w), ptr(mask), ptr(dx), nb, hout, 32 * hin * hin, hin * hin, hin,
                                          0, _stream()), "drq_conv3x3_dgrad_bf16")

@@ -64,6 +64,13 @@ int drq_conv3x3_fwd(const float* x, const float* w, const float* bias, float* y,
  * [nb][32][hout+4][hout+4].  dx (size hout+2) = conv_transpose(dy, w) * (mask > 0), strided store. */
 int drq_conv3x3_dgrad(const float* dy_pad, const float* w, const float* mask, float* dx, int nb, int hout,
                       long dx_bs, long dx_cs, long dx_rs, long dx_off, drq_stream_t stream);
+/* The 32->32 layers (hin 41/39/37, stride 1) and their input gradient in Winograd F(2x2,3x3) form: same contracts as
+ * drq_conv3x3_fwd / drq_conv3x3_dgrad, 2.25x fewer matrix FLOPs, fp32 throughout; the result differs from the
+ * direct form by rounding only (same error level against fp64).  This is what DrQV2Agent.update runs. */
+int drq_conv3x3_fwd_wino(const float* x, const float* w, const float* bias, float* y, int nb, int hin, int relu,
+                         long y_bs, long y_cs, long y_rs, long y_off, drq_stream_t stream);
+int drq_conv3x3_dgrad_wino(const float* dy_pad, const float* w, const float* mask, float* dx, int nb, int hout,
+                           long dx_bs, long dx_cs, long dx_rs, long dx_off, drq_stream_t stream);
 /* dw [32][cin][3][3], db [32]; dy addressed as dy[dy_off + b*dy_bs + co*dy_cs + oy*dy_rs + ox]. */
 int drq_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, int nb, int cin, int hin,
                       int stride, long dy_bs, long dy_cs, long dy_rs, long dy_off, float* ws, size_t ws_bytes,

@@ -105,6 +105,47 @@ def test_conv_dgrad(ops, hout, nb):
     assert nerr(dx2, F.conv_transpose2d(dy.double(), w.double())) <= 2e-6
 
 
+@pytest.mark.parametrize("hin,nb", [(41, 3), (39, 4), (37, 2), (41, 1), (37, 33)])
+def test_conv_fwd_winograd(ops, hin, nb):
+    """The update's form of the 32->32 layers (Winograd F(2x2,3x3), drq_conv3x3_fwd_wino): same bound against fp64 as
+    the direct kernel, ragged last tile row / column (the output sizes are odd), ragged last unit of 16 tiles."""
+    x = rnd(nb, 32, hin, hin, seed=1)
+    w = rnd(32, 32, 3, 3, seed=2, scale=0.2)
+    b = rnd(32, seed=3, scale=0.1)
+    y = ops.conv3x3_fwd(x.cuda(), w.cuda(), b.cuda(), 1, relu=True, wino=True)
+    ref = torch.relu(F.conv2d(x.double(), w.double(), b.double()))
+    assert nerr(y, ref) <= 2e-6
+    y2 = ops.conv3x3_fwd(x.cuda(), w.cuda(), b.cuda(), 1, relu=False, wino=True)
+    assert nerr(y2, F.conv2d(x.double(), w.double(), b.double())) <= 2e-6
+    # against the direct kernel: rounding-level difference only
+    assert nerr(y2, ops.conv3x3_fwd(x.cuda(), w.cuda(), b.cuda(), 1, relu=False).double().cpu()) <= 2e-6
+
+
+@pytest.mark.parametrize("hout,nb", [(35, 3), (37, 2), (39, 5), (35, 19)])
+def test_conv_dgrad_winograd(ops, hout, nb):
+    hin = hout + 2
+    dy = rnd(nb, 32, hout, hout, seed=4)
+    w = rnd(32, 32, 3, 3, seed=5, scale=0.2)
+    act = rnd(nb, 32, hin, hin, seed=6).clamp_min(0)          # post-ReLU input of the layer
+    dy_pad = F.pad(dy, (2, 2, 2, 2)).contiguous()
+    dx = ops.conv3x3_dgrad(dy_pad.cuda(), w.cuda(), act.cuda(), wino=True)
+    ref = F.conv_transpose2d(dy.double(), w.double()) * (act > 0).double()
+    assert nerr(dx, ref) <= 2e-6
+    dx2 = ops.conv3x3_dgrad(dy_pad.cuda(), w.cuda(), None, wino=True)
+    assert nerr(dx2, F.conv_transpose2d(dy.double(), w.double())) <= 2e-6
+    # strided (padded) destination, as the update writes it: the border must stay untouched
+    lib, hp = ops._lib.load(), hin + 4
+    dst = torch.full((nb, 32, hp, hp), 7.0, device="cuda")
+    dyc, wc, ac = dy_pad.cuda(), w.cuda(), act.cuda()
+    ops.check(lib.drq_conv3x3_dgrad_wino(dyc.data_ptr(), wc.data_ptr(), ac.data_ptr(), dst.data_ptr(), nb, hout,
+                                         32 * hp * hp, hp * hp, hp, 2 * hp + 2, None), "wino")
+    torch.cuda.synchronize()
+    assert torch.equal(dst[:, :, 2:-2, 2:-2].cpu(), dx.cpu())
+    border = dst.clone()
+    border[:, :, 2:-2, 2:-2] = 7.0
+    assert bool((border == 7.0).all())
+
+
 @pytest.mark.parametrize("cin,hin,stride,nb", [(9, 84, 2, 3), (32, 41, 1, 5), (32, 39, 1, 2), (32, 37, 1, 7)])
 def test_conv_wgrad(ops, cin, hin, stride, nb):
     hout = (hin - 3) // stride + 1
