@@ -34,7 +34,13 @@ typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
 typedef float f32x2w __attribute__((ext_vector_type(2)));
 
-template <int HIN, bool MASK>
+#ifdef DRQ_DEV
+int g_wino_variant = 0;   // drq_dev_wino_variant: timing ablations (tools/wino_bench.py)
+#endif
+
+// ABL (development build only): 1 = no input transform (V = d), 2 = no output transform (position 0 is stored),
+// 4 = no patch loads; the results are wrong on purpose
+template <int HIN, bool MASK, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
 #pragma clang fp contract(off)
   constexpr int HOUT = HIN - 2;
@@ -50,20 +56,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   const int kk = lane >> 4;     // input channel inside the k-step (A/B k index); D rows 4*kk + r
 
   // ---- U = G g G^T for the 1024 (cout, cin) filters -> LDS
-  for (int q = tid; q < 1024; q += 256) {
-    const int oc = q >> 5, ic = q & 31;      // output channel (A row) / reduction channel of THIS product
-    float g[9];
-    if (a.wmode == 0) {
+  // The canonical weights are copied into LDS first (contiguous global reads; rows of 32 filters at a pitch of 289
+  // floats), every thread then pulls the nine taps of its four filters into registers, and only after a barrier is
+  // the same memory overwritten with U.  Lanes walk the OUTPUT channel: the staging reads are conflict-free in both
+  // gather modes (row pitch 289 / filter pitch 9, both odd) and the U writes land in 32 distinct banks per half-wave
+  // (a lane-ordered gather from global memory costs several us per workgroup, and so did U writes that walked the
+  // input channel: 32 lanes on one bank).
+  constexpr int SP = 289;
+  for (int i = tid; i < 32 * 288; i += 256) U[(i / 288) * SP + (i % 288)] = a.w[i];
+  __syncthreads();
+  float g[4][9];
 #pragma unroll
-      for (int t = 0; t < 9; ++t) g[t] = a.w[(oc * 32 + ic) * 9 + t];
-    } else {
+  for (int it = 0; it < 4; ++it) {
+    const int q = it * 256 + tid;
+    const int oc = q & 31, ic = q >> 5;      // output channel (A row) / reduction channel of THIS product
+    const float* src = a.wmode == 0 ? U + oc * SP + ic * 9 : U + ic * SP + oc * 9;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) g[t] = a.w[(ic * 32 + oc) * 9 + (8 - t)];
-    }
+    for (int t = 0; t < 9; ++t) g[it][t] = src[a.wmode == 0 ? t : 8 - t];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int q = it * 256 + tid;
+    const int oc = q & 31, ic = q >> 5;
     float tm[4][3];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
-      const float g0 = g[kx], g1 = g[3 + kx], g2 = g[6 + kx];
+      const float g0 = g[it][kx], g1 = g[it][3 + kx], g2 = g[it][6 + kx];
       tm[0][kx] = g0;
       tm[1][kx] = 0.5f * ((g0 + g2) + g1);
       tm[2][kx] = 0.5f * ((g0 + g2) - g1);
@@ -109,6 +128,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   auto load_patch = [&](float (&d)[16], int voff, int c) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      if constexpr (ABL & 4) {
+        d[i * 4 + 0] = 1.0f + (float)(voff + c); d[i * 4 + 1] = 2.0f + (float)(voff + i);
+        d[i * 4 + 2] = 1.5f + (float)voff; d[i * 4 + 3] = (float)(c + i);
+        continue;
+      }
       const u32x4w v = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, c * (4 * PLANE) + i * (HIN * 4), 0);
       const unsigned e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];
       d[i * 4 + 0] = __uint_as_float(e0);
@@ -145,6 +169,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
       float t[16];                           // B^T d
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
+        if constexpr (ABL & 1) {
+          t[0 * 4 + j] = d[0 * 4 + j]; t[1 * 4 + j] = d[1 * 4 + j]; t[2 * 4 + j] = d[2 * 4 + j]; t[3 * 4 + j] = d[3 * 4 + j];
+          continue;
+        }
         t[0 * 4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
         t[1 * 4 + j] = d[1 * 4 + j] + d[2 * 4 + j];
         t[2 * 4 + j] = d[2 * 4 + j] - d[1 * 4 + j];
@@ -158,6 +186,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
       float V[16];                           // (B^T d) B, all of it ahead of the MFMAs (no VALU->MFMA hazard per use)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
+        if constexpr (ABL & 1) {
+          V[i * 4 + 0] = t[i * 4 + 0]; V[i * 4 + 1] = t[i * 4 + 1]; V[i * 4 + 2] = t[i * 4 + 2]; V[i * 4 + 3] = t[i * 4 + 3];
+          continue;
+        }
         V[i * 4 + 0] = t[i * 4 + 0] - t[i * 4 + 2];
         V[i * 4 + 1] = t[i * 4 + 1] + t[i * 4 + 2];
         V[i * 4 + 2] = t[i * 4 + 2] - t[i * 4 + 1];
@@ -198,6 +230,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
       const int ybase = (a.y_off + b * a.y_bs + (4 * kk) * a.y_cs + (2 * ty) * a.y_rs + 2 * tx) * 4;
       const int mbase = (((b * 32 + 4 * kk) * HOUT + 2 * ty) * HOUT + 2 * tx) * 4;
       const bool edge = __builtin_amdgcn_ballot_w64(valid && !c1ok) != 0;
+      if constexpr (ABL & 2) {               // every accumulator stays live although only four are stored
+#pragma unroll
+        for (int pos = 0; pos < 16; ++pos) asm volatile("" ::"v"(acc[pos][0]), "v"(acc[pos][1]));
+      }
       // the ReLU mask of the layer below: all 16 loads go out before the transform arithmetic
       u32x2w mk[2][4][2];
       if constexpr (MASK) {
@@ -220,14 +256,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
           for (int j = 0; j < 4; ++j) {
             const float m0 = acc[0 * 4 + j][h][r], m1 = acc[1 * 4 + j][h][r], m2 = acc[2 * 4 + j][h][r],
                         m3 = acc[3 * 4 + j][h][r];
-            s[0][j] = (m0 + m1) + m2;
-            s[1][j] = (m1 - m2) - m3;
+            s[0][j] = (ABL & 2) ? m0 : (m0 + m1) + m2;
+            s[1][j] = (ABL & 2) ? m0 + m3 : (m1 - m2) - m3;
           }
           const int co = (16 * h + r);       // + 4*kk rides in the lane's base offset
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
-            float y0 = (s[i][0] + s[i][1]) + s[i][2];
-            float y1 = (s[i][1] - s[i][2]) - s[i][3];
+            float y0 = (ABL & 2) ? s[i][0] : (s[i][0] + s[i][1]) + s[i][2];
+            float y1 = (ABL & 2) ? s[i][3] : (s[i][1] - s[i][2]) - s[i][3];
             if (a.relu) {
               y0 = y0 > 0.f ? y0 : 0.f;
               y1 = y1 > 0.f ? y1 : 0.f;
@@ -257,6 +293,19 @@ int launch_wino(const WinoArgs& a, hipStream_t st) {
   const long cap = 2L * drq_num_cus();
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
+#ifdef DRQ_DEV
+  if (!a.mask && g_wino_variant) {
+    switch (g_wino_variant) {
+      case 1: hipLaunchKernelGGL((conv3x3_wino_kernel<HIN, false, 1>), dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+      case 2: hipLaunchKernelGGL((conv3x3_wino_kernel<HIN, false, 2>), dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+      case 3: hipLaunchKernelGGL((conv3x3_wino_kernel<HIN, false, 3>), dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+      case 4: hipLaunchKernelGGL((conv3x3_wino_kernel<HIN, false, 4>), dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+      default: hipLaunchKernelGGL((conv3x3_wino_kernel<HIN, false, 7>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    }
+    DRQ_LAUNCH_CHECK();
+    return DRQ_OK;
+  }
+#endif
   if (a.mask) hipLaunchKernelGGL((conv3x3_wino_kernel<HIN, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((conv3x3_wino_kernel<HIN, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
   DRQ_LAUNCH_CHECK();
@@ -264,6 +313,10 @@ int launch_wino(const WinoArgs& a, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef DRQ_DEV
+extern "C" DRQ_API void drq_dev_wino_variant(int v) { g_wino_variant = v; }
+#endif
 
 extern "C" {
 

@@ -300,6 +300,9 @@ int encoder_forward(const Ctx& c, const float* x, int nb, float* a1, float* a2, 
     if (c.bf16() && l > 0)
       CK(drq_conv3x3_fwd_bf16(in, c.p(P.enc_w[l]), c.p(P.enc_b[l]), outs[l], nb, hin, 1, 32L * hout * hout,
                               (long)hout * hout, hout, 0, c.st));
+    else if (l > 0)   // the 32->32 layers in Winograd F(2x2,3x3) form (conv_wino.hip)
+      CK(drq_conv3x3_fwd_wino(in, c.p(P.enc_w[l]), c.p(P.enc_b[l]), outs[l], nb, hin, 1, 32L * hout * hout,
+                              (long)hout * hout, hout, 0, c.st));
     else
     CK(drq_conv3x3_fwd(in, c.p(P.enc_w[l]), c.p(P.enc_b[l]), outs[l], nb, l == 0 ? c.s->C : 32, hin, l == 0 ? 2 : 1,
                        1, 32L * hout * hout, (long)hout * hout, hout, 0, c.st));
@@ -534,8 +537,8 @@ int phase_conv_backward(const Ctx& c) {
         CK(drq_conv3x3_dgrad_bf16(dy, c.p(P.enc_w[l]), c.ws(actid[l]), c.ws(dyid[l - 1]), B, hout, 32L * hpi * hpi,
                                   (long)hpi * hpi, hpi, 2L * hpi + 2, st));
       else
-      CK(drq_conv3x3_dgrad(dy, c.p(P.enc_w[l]), c.ws(actid[l]), c.ws(dyid[l - 1]), B, hout, 32L * hpi * hpi,
-                           (long)hpi * hpi, hpi, 2L * hpi + 2, st));
+      CK(drq_conv3x3_dgrad_wino(dy, c.p(P.enc_w[l]), c.ws(actid[l]), c.ws(dyid[l - 1]), B, hout, 32L * hpi * hpi,
+                                (long)hpi * hpi, hpi, 2L * hpi + 2, st));
       if (ev && l == 2 && hipEventRecord((hipEvent_t)ev[3], st) != hipSuccess) return DRQ_EARG;
     }
   }

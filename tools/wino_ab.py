@@ -1,0 +1,37 @@
+"""Timing ablations of conv3x3_wino_kernel (development build): which part of the unit time is the input transform,
+the output transform, the patch loads.  Usage: python tools/wino_ab.py [B]"""
+import ctypes, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from drqv2_amd import _lib
+lib = _lib.load(dev=True)
+from drqv2_amd import ops
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+g = torch.Generator(device="cuda").manual_seed(0)
+rn = lambda *s: torch.randn(*s, device="cuda", generator=g)
+w, b = rn(32, 32, 3, 3) * 0.1, rn(32) * 0.1
+x = rn(2 * B, 32, 41, 41).clamp_min(0)
+
+
+def timeit(fn, n=40):
+    for _ in range(8):
+        fn()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(n):
+        fn()
+    ev[1].record()
+    torch.cuda.synchronize()
+    return ev[0].elapsed_time(ev[1]) / n * 1e3
+
+
+names = {0: "full", 1: "no input transform", 2: "no output transform", 3: "no transforms", 4: "no patch loads",
+         7: "MFMA + LDS operand reads only"}
+lib.drq_dev_wino_variant.argtypes = [ctypes.c_int]
+for rep in range(2):
+    for v in (0, 1, 2, 3, 4, 7):
+        lib.drq_dev_wino_variant(v)
+        print(f"variant {v} ({names[v]:30s}): {timeit(lambda: ops.conv3x3_fwd(x, w, b, 1, wino=True)):7.1f} us", flush=True)
+lib.drq_dev_wino_variant(0)
