@@ -11,6 +11,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdrqv2_hip.so")
 LIB_DEV = os.path.join(HERE, "libdrqv2_hip_dev.so")
 SOURCES = ["conv.hip", "conv_wino.hip", "conv1aug.hip", "conv_bf16.hip", "gemm.hip", "gemm2.hip", "skinny.hip", "elementwise.hip", "step.hip"]
+# per-file additions.  conv_wino.hip: hipcc's SLP vectoriser packs the transform adds into v_pk_add_f32 plus the
+# v_mov shuffles that feed them -- more VALU issue slots beside the MFMAs, not fewer (136 moves per unit)
+FILE_FLAGS = {"conv_wino.hip": ["-fno-slp-vectorize"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-fvisibility=hidden"]
 
@@ -44,7 +47,7 @@ def build(force=False, verbose=True, dev=False):
     procs = []
     for src in _sources():
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [_hipcc()] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [_hipcc()] + flags + FILE_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((obj, subprocess.Popen(cmd)))

@@ -28,6 +28,8 @@ struct WinoArgs {
   int nb;
   int relu;
   int wmode;           // 0 forward gather, 1 dgrad gather (transposed + flipped)
+  int stagger;         // start delay of the second wave of each SIMD, in units of 1024 clocks (see the kernel)
+  unsigned long long* stamps;   // development only (ABL & 8): 32 per wave
 };
 
 typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
@@ -36,11 +38,15 @@ typedef float f32x2w __attribute__((ext_vector_type(2)));
 
 #ifdef DRQ_DEV
 int g_wino_variant = 0;   // drq_dev_wino_variant: timing ablations (tools/wino_bench.py)
+int g_wino_stagger = -1;  // drq_dev_wino_stagger: overrides kStagger
+unsigned long long* g_wino_stamps = nullptr;
 #endif
+constexpr int kStagger = 0;
 
 // ABL (development build only): 1 = no input transform (V = d), 2 = no output transform (position 0 is stored),
-// 4 = no patch loads; the results are wrong on purpose
-template <int HIN, bool MASK, int ABL = 0>
+// 4 = no patch loads; the results are wrong on purpose; 8 = per-wave s_memtime stamps (start, after the prologue,
+// after every unit; [29],[30] = s_memrealtime end / start, [31] = HW_ID)
+template <int HIN, bool MASK, bool RELU, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
 #pragma clang fp contract(off)
   constexpr int HOUT = HIN - 2;
@@ -52,6 +58,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = tid >> 6;
+  unsigned long long* stamp = nullptr;
+  int nstamp = 0;
+  auto mark = [&]() {
+    if constexpr (ABL & 8) {
+      if (stamp && nstamp < 28 && lane == 0) stamp[nstamp] = __builtin_amdgcn_s_memtime();
+      ++nstamp;
+    }
+  };
+  if constexpr (ABL & 8) {
+    if (a.stamps) {
+      stamp = a.stamps + ((size_t)blockIdx.x * 4 + wid) * 32;
+      if (lane == 0) {
+        stamp[30] = __builtin_amdgcn_s_memrealtime();
+        stamp[31] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+        stamp[28] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // XCC_ID
+      }
+    }
+  }
+  mark();
   const int tl = lane & 15;     // tile of the unit (B column / D column)
   const int kk = lane >> 4;     // input channel inside the k-step (A/B k index); D rows 4*kk + r
 
@@ -107,6 +132,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
     for (int r = 0; r < 4; ++r) bv[h][r] = a.bias ? a.bias[16 * h + 4 * kk + r] : 0.f;
   __syncthreads();
 
+  // The two waves of a SIMD come from two workgroups that start together and run the same program: left alone they
+  // stay in lockstep -- both in their transform / epilogue phases at the same time, the matrix pipe idle meanwhile.
+  // The wave in the odd slot of its SIMD (HW_ID bits 3:0) starts late, so that one wave's non-matrix phases fall
+  // into the other's MFMA runs.  Speed only.
+  if (a.stagger) {
+    const unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+    if (hwid & 1u)
+      for (int q = 0; q < a.stagger; ++q) __builtin_amdgcn_s_sleep(16);
+  }
+
+  mark();
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, a.y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t mrs =
@@ -229,7 +265,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
       const bool c1ok = 2 * tx + 1 < HOUT, r1ok = 2 * ty + 1 < HOUT;
       const int ybase = (a.y_off + b * a.y_bs + (4 * kk) * a.y_cs + (2 * ty) * a.y_rs + 2 * tx) * 4;
       const int mbase = (((b * 32 + 4 * kk) * HOUT + 2 * ty) * HOUT + 2 * tx) * 4;
-      const bool edge = __builtin_amdgcn_ballot_w64(valid && !c1ok) != 0;
+      // per-lane store offsets of the unit: [row][8-byte pair | lone first column of the last tile of a row]
+      // (invalid -> beyond num_records: the buffer unit drops the store; no branches in the epilogue)
+      int o64[2], o32[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bool rowok = valid && (i == 0 || r1ok);
+        o64[i] = (rowok && c1ok) ? ybase : kDrop;
+        o32[i] = (rowok && !c1ok) ? ybase : kDrop;
+      }
       if constexpr (ABL & 2) {               // every accumulator stays live although only four are stored
 #pragma unroll
         for (int pos = 0; pos < 16; ++pos) asm volatile("" ::"v"(acc[pos][0]), "v"(acc[pos][1]));
@@ -247,6 +291,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
                                                                  (16 * h + r) * (HOUT * HOUT * 4), 0);
         __builtin_amdgcn_sched_barrier(0);
       }
+      const int ycs4 = a.y_cs * 4, yrs4 = a.y_rs * 4;
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -264,29 +309,38 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
           for (int i = 0; i < 2; ++i) {
             float y0 = (ABL & 2) ? s[i][0] : (s[i][0] + s[i][1]) + s[i][2];
             float y1 = (ABL & 2) ? s[i][3] : (s[i][1] - s[i][2]) - s[i][3];
-            if (a.relu) {
-              y0 = y0 > 0.f ? y0 : 0.f;
-              y1 = y1 > 0.f ? y1 : 0.f;
+            if constexpr (RELU) {
+              y0 = __builtin_fmaxf(y0, 0.f);
+              y1 = __builtin_fmaxf(y1, 0.f);
             }
             if constexpr (MASK) {
               const unsigned q0 = mk[h][r][i][0], q1 = mk[h][r][i][1];
               y0 = __uint_as_float(q0) > 0.f ? y0 : 0.f;
               y1 = __uint_as_float(q1) > 0.f ? y1 : 0.f;
             }
-            const bool rowok = valid && (i == 0 || r1ok);
-            const int soff = (co * a.y_cs + i * a.y_rs) * 4;       // wave-uniform: scalar offset
+            const int soff = co * ycs4 + i * yrs4;                 // wave-uniform: scalar offset
             const u32x2w pk = {__float_as_uint(y0), __float_as_uint(y1)};
-            __builtin_amdgcn_raw_buffer_store_b64(pk, yrs, (rowok && c1ok) ? ybase : kDrop, soff, 0);
-            if (edge) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y0), yrs, (rowok && !c1ok) ? ybase : kDrop, soff, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(pk, yrs, o64[i], soff, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y0), yrs, o32[i], soff, 0);
           }
         }
     }
     voff = nvoff;
+    mark();
+  }
+  if constexpr (ABL & 8) {
+    __builtin_amdgcn_s_waitcnt(0);
+    if (stamp && lane == 0) stamp[29] = __builtin_amdgcn_s_memrealtime();
   }
 }
 
 template <int HIN>
-int launch_wino(const WinoArgs& a, hipStream_t st) {
+int launch_wino(const WinoArgs& a0, hipStream_t st) {
+  WinoArgs a = a0;
+  a.stagger = kStagger;
+#ifdef DRQ_DEV
+  if (g_wino_stagger >= 0) a.stagger = g_wino_stagger;
+#endif
   constexpr int HOUT = HIN - 2, TH = (HOUT + 1) / 2;
   const long nunit = ((long)a.nb * TH * TH + 15) / 16;
   long blocks = (nunit + 3) / 4;
@@ -294,20 +348,25 @@ int launch_wino(const WinoArgs& a, hipStream_t st) {
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
 #ifdef DRQ_DEV
-  if (!a.mask && g_wino_variant) {
+  if (!a.mask && a.relu && g_wino_variant) {
     switch (g_wino_variant) {
-      case 1: hipLaunchKernelGGL((conv3x3_wino_kernel<HIN, false, 1>), dim3((unsigned)blocks), dim3(256), 0, st, a); break;
-      case 2: hipLaunchKernelGGL((conv3x3_wino_kernel<HIN, false, 2>), dim3((unsigned)blocks), dim3(256), 0, st, a); break;
-      case 3: hipLaunchKernelGGL((conv3x3_wino_kernel<HIN, false, 3>), dim3((unsigned)blocks), dim3(256), 0, st, a); break;
-      case 4: hipLaunchKernelGGL((conv3x3_wino_kernel<HIN, false, 4>), dim3((unsigned)blocks), dim3(256), 0, st, a); break;
-      default: hipLaunchKernelGGL((conv3x3_wino_kernel<HIN, false, 7>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+      case 1: hipLaunchKernelGGL((conv3x3_wino_kernel<HIN, false, true, 1>), dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+      case 2: hipLaunchKernelGGL((conv3x3_wino_kernel<HIN, false, true, 2>), dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+      case 3: hipLaunchKernelGGL((conv3x3_wino_kernel<HIN, false, true, 3>), dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+      case 4: hipLaunchKernelGGL((conv3x3_wino_kernel<HIN, false, true, 4>), dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+      case 8: a.stamps = g_wino_stamps; hipLaunchKernelGGL((conv3x3_wino_kernel<HIN, false, true, 8>), dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+      case 15: a.stamps = g_wino_stamps; hipLaunchKernelGGL((conv3x3_wino_kernel<HIN, false, true, 15>), dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+      default: hipLaunchKernelGGL((conv3x3_wino_kernel<HIN, false, true, 7>), dim3((unsigned)blocks), dim3(256), 0, st, a);
     }
     DRQ_LAUNCH_CHECK();
     return DRQ_OK;
   }
 #endif
-  if (a.mask) hipLaunchKernelGGL((conv3x3_wino_kernel<HIN, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((conv3x3_wino_kernel<HIN, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  const dim3 g((unsigned)blocks), t(256);
+  if (a.mask && a.relu) hipLaunchKernelGGL((conv3x3_wino_kernel<HIN, true, true>), g, t, 0, st, a);
+  else if (a.mask) hipLaunchKernelGGL((conv3x3_wino_kernel<HIN, true, false>), g, t, 0, st, a);
+  else if (a.relu) hipLaunchKernelGGL((conv3x3_wino_kernel<HIN, false, true>), g, t, 0, st, a);
+  else hipLaunchKernelGGL((conv3x3_wino_kernel<HIN, false, false>), g, t, 0, st, a);
   DRQ_LAUNCH_CHECK();
   return DRQ_OK;
 }
@@ -316,6 +375,8 @@ int launch_wino(const WinoArgs& a, hipStream_t st) {
 
 #ifdef DRQ_DEV
 extern "C" DRQ_API void drq_dev_wino_variant(int v) { g_wino_variant = v; }
+extern "C" DRQ_API void drq_dev_wino_stagger(int v) { g_wino_stagger = v; }
+extern "C" DRQ_API void drq_dev_wino_stamps(void* p) { g_wino_stamps = (unsigned long long*)p; }
 #endif
 
 extern "C" {
@@ -327,7 +388,7 @@ DRQ_API int drq_conv3x3_fwd_wino(const float* x, const float* w, const float* bi
   const size_t xb = (size_t)nb * 32 * hin * hin * 4;
   const size_t yb = (size_t)nb * y_bs * 4;
   if (xb >= (1ull << 31) || yb >= (1ull << 31) || y_off < 0 || y_bs <= 0) return DRQ_EARG;
-  WinoArgs a{x, w, bias, nullptr, y, (int)y_bs, (int)y_cs, (int)y_rs, (int)y_off, (unsigned)xb, (unsigned)yb, 0u, nb, relu, 0};
+  WinoArgs a{x, w, bias, nullptr, y, (int)y_bs, (int)y_cs, (int)y_rs, (int)y_off, (unsigned)xb, (unsigned)yb, 0u, nb, relu, 0, 0, nullptr};
   if (hin == 41) return launch_wino<41>(a, st);
   if (hin == 39) return launch_wino<39>(a, st);
   if (hin == 37) return launch_wino<37>(a, st);
@@ -344,7 +405,7 @@ DRQ_API int drq_conv3x3_dgrad_wino(const float* dy_pad, const float* w, const fl
   const size_t mb = (size_t)nb * 32 * (hout + 2) * (hout + 2) * 4;
   if (xb >= (1ull << 31) || yb >= (1ull << 31) || dx_off < 0 || dx_bs <= 0) return DRQ_EARG;
   WinoArgs a{dy_pad, w, nullptr, mask, dx, (int)dx_bs, (int)dx_cs, (int)dx_rs, (int)dx_off, (unsigned)xb, (unsigned)yb,
-             (unsigned)mb, nb, 0, 1};
+             (unsigned)mb, nb, 0, 1, 0, nullptr};
   if (hp == 39) return launch_wino<39>(a, st);
   if (hp == 41) return launch_wino<41>(a, st);
   if (hp == 43) return launch_wino<43>(a, st);

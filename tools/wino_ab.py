@@ -35,3 +35,13 @@ for rep in range(2):
         lib.drq_dev_wino_variant(v)
         print(f"variant {v} ({names[v]:30s}): {timeit(lambda: ops.conv3x3_fwd(x, w, b, 1, wino=True)):7.1f} us", flush=True)
 lib.drq_dev_wino_variant(0)
+lib.drq_dev_wino_stagger.argtypes = [ctypes.c_int]
+dyp = torch.zeros(B, 32, 41, 41, device="cuda")
+dyp[:, :, 2:-2, 2:-2] = rn(B, 32, 37, 37)
+mask = rn(B, 32, 39, 39)
+for rep in range(2):
+    for sg in (0, 1, 2, 4, 6, 9, 12):
+        lib.drq_dev_wino_stagger(sg)
+        tf = timeit(lambda: ops.conv3x3_fwd(x, w, b, 1, wino=True))
+        td = timeit(lambda: ops.conv3x3_dgrad(dyp, w, mask, wino=True))
+        print(f"stagger {sg:2d} x 1024 clocks: fwd hin 41 {tf:7.1f} us   dgrad hout 37 {td:7.1f} us", flush=True)
