@@ -16,8 +16,11 @@ replay batches.  Contract: python bench.py --gpus N --steps K --warmup W  ->  ON
               hidden under compute.  The same line carries `weak` (256 samples PER GPU, value
               = global samples/s / 256) and `n1_same_workload` (rank 0 alone on the plain single-GPU path, same
               job, same box).  --workload / --task / --batch / --weak override.
-  roofline  = dominant kernel conv3x3_kernel<32,41,1> (conv2 forward on both views + conv3 dgrad), timed live
-              with events on the launch stream; algorithmic FLOPs = 2*32*288 per output pixel.
+  roofline  = dominant kernel conv3x3_wino_kernel<41> (conv2 forward on both views + conv3 dgrad, Winograd F(2x2,3x3)
+              on the f32 MFMA), timed live with events on the launch stream.  `achieved` counts the matrix FLOPs the
+              kernel EXECUTES (256 v_mfma_f32_16x16x4_f32 per 16 output tiles), so `frac` is a true fraction of the MFMA
+              peak; `direct_equiv_tflops` is the direct-form work (2*32*288 per output pixel) over the same
+              time, which Winograd's 2.25x saving can push past the peak.
   cpu_baseline = the CPU oracle (oracle/drq_oracle.py, kind "port") on the host cores, rank 0, N=1 only.
 """
 import argparse
@@ -331,7 +334,7 @@ def conv_traffic():
 
 
 def roofline_conv(agent, B, it, step):
-    """conv3x3_kernel<32,41,1>: its two launches per update (conv2 forward on 2B frames, conv3 dgrad on B), timed
+    """conv3x3_wino_kernel<41,...>: its two launches per update (conv2 forward on 2B frames, conv3 dgrad on B), timed
     IN the update with HIP events the library records around those two launches on the stream they run on
     (DrqStep.timing_events).  In isolation, back to back, the same launches run ~10 % slower (the chip holds a
     lower clock under an MFMA-only load than inside the update's mix of kernels), and rocprofv3's per-kernel
@@ -359,21 +362,29 @@ def roofline_conv(agent, B, it, step):
     t_d /= n
     traffic, note = None, None
     tr = conv_traffic()
-    names = ("conv3x3_kernel<32, 41, 1, 2, 1, 0, false>", "conv3x3_kernel<32, 41, 1, 2, 1, 0, true>")   # fwd 2B, dgrad B
+    names = ("conv3x3_wino_kernel<41, false, true, 0>", "conv3x3_wino_kernel<41, true, false, 0>")   # fwd 2B, dgrad B
     if tr is not None and B == tr.get("B") and all(n in tr.get("kernels", {}) for n in names):
         per = [(2 * tr["kernels"][n]["FETCH_SIZE_KB"] + tr["kernels"][n]["WRITE_SIZE_KB"]) * 1024 for n in names]
         traffic = sum(per) / len(per)
         note = (f"bytes per launch, mean of the two launches, (2*FETCH_SIZE+WRITE_SIZE)*1024 from separate --pmc passes of "
                 f"the bench at B={tr['B']} (profiles/kernel_traffic.json, measured at commit {tr.get('commit')}); "
-                "algorithmic bytes are 210 MB (fwd) / 155 MB (dgrad); the x2 on FETCH_SIZE is calibrated for 16-byte lane "
-                "loads, this kernel uses 12-byte ones (F+W alone: "
-                f"{sum((tr['kernels'][n]['FETCH_SIZE_KB'] + tr['kernels'][n]['WRITE_SIZE_KB']) * 1024 for n in names) / 2 / 1e6:.0f} MB)")
-    fl_f = 2 * 32 * 288 * (2 * B) * 39 * 39
+                "algorithmic bytes are 210 MB (fwd: 110 in + 100 out) / 155 MB (dgrad: 55 in + 50 mask + 50 out)")
+    # executed matrix work: a unit = 16 output tiles (2x2 pixels each) x 32 channels x 16 positions x 8 k-steps
+    # = 256 v_mfma_f32_16x16x4_f32 of 2*16*16*4 FLOP; 20x20 tiles cover the 39x39 outputs of a frame
+    units_f, units_d = (2 * B * 400 + 15) // 16, (B * 400 + 15) // 16
+    ex_f, ex_d = units_f * 256 * 2048, units_d * 256 * 2048
+    fl_f = 2 * 32 * 288 * (2 * B) * 39 * 39          # the direct form's FLOPs for the same outputs
     fl_d = 2 * 32 * 288 * B * 39 * 39
-    ach = (fl_f + fl_d) / (t_f + t_d) / 1e12
-    return {"kernel": "conv3x3_kernel<32,41,1>", "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS,
+    ach = (ex_f + ex_d) / (t_f + t_d) / 1e12
+    return {"kernel": "conv3x3_wino_kernel<41> (Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32)", "bound": "mfma",
+            "achieved": ach, "peak": PEAK_FP32_TFLOPS,
             "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_note": note,
+            "achieved_counts": "matrix FLOPs the kernel executes (Winograd needs 16/36 of the direct form's, on 20x20 "
+                               "tiles of 2x2 for 39x39 outputs); the VALU transforms (56 adds per tile and channel) "
+                               "share the f32 datapath with the MFMA and are not counted",
+            "direct_equiv_tflops": (fl_f + fl_d) / (t_f + t_d) / 1e12,
             "avg_launch_us": 0.5e6 * (t_f + t_d), "launch_us": {"conv2_fwd_2B": 1e6 * t_f, "conv3_dgrad_B": 1e6 * t_d},
+            "executed_gflop_per_launch": {"conv2_fwd_2B": ex_f / 1e9, "conv3_dgrad_B": ex_d / 1e9},
             "alg_gflop_per_launch": {"conv2_fwd_2B": fl_f / 1e9, "conv3_dgrad_B": fl_d / 1e9}, "frames_per_launch": B,
             "timing": "hipEvent pairs recorded by the library around the two launches inside 20 update() calls"}
 

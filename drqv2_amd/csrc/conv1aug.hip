@@ -17,6 +17,7 @@
 // k order and accumulation order are those of conv3x3_kernel<9,84,2>: the results are bit-identical to the
 // unfused path (tests/test_hip_ops.py).
 #include "common.h"
+#include "wino_u.h"
 #include <stdio.h>
 
 namespace {
@@ -58,6 +59,12 @@ struct Conv1AugArgs {
   int n, n_store;
   unsigned y_bytes;
   int stagger;               // start delay of the second half of the grid, in units of 127*64 clocks
+  // riders: the first n_rider (0 or 6) workgroups do not touch frames; workgroup 2*l + m writes the Winograd image of
+  // layer l+2's weights (m = 0 forward, 1 input-gradient form) to wino_u + (2*l + m)*16384 (wino_u.h).  The three
+  // 32->32 layers of THIS update read them instead of transforming the weights in every workgroup's prologue.
+  const float* wino_w[3];
+  float* wino_u;
+  int n_rider;
   unsigned long long* stamps;   // development build: [grid][4] = start, end (s_memrealtime), HW_ID, XCC_ID
 };
 
@@ -99,8 +106,14 @@ __global__ __launch_bounds__(NTHR, 2 * NTHR / 256) void conv1_aug_kernel(Conv1Au
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 31, half = lane >> 5;
+  if ((int)blockIdx.x < a.n_rider) {         // wave-uniform: the whole workgroup takes the rider's path
+    const int job = blockIdx.x;
+    wino_u_image<false>(a.wino_w[job >> 1], job & 1, smem, a.wino_u + (size_t)job * 16384, tid);
+    return;
+  }
+  const int bid = (int)blockIdx.x - a.n_rider;
   const int units = 2 * a.n * NBAND;
-  const int G = (int)gridDim.x;
+  const int G = (int)gridDim.x - a.n_rider;
 
 #ifdef DRQ_DEV
   if (a.stamps && tid == 0) {
@@ -111,7 +124,7 @@ __global__ __launch_bounds__(NTHR, 2 * NTHR / 256) void conv1_aug_kernel(Conv1Au
 #endif
   if (tid < H) bg[tid] = a.base[tid];
   if (tid >= 128 && tid < 128 + MAXU) {                            // the host sizes the grid so that MAXU covers them
-    const int k = tid - 128, uu = blockIdx.x + k * G;
+    const int k = tid - 128, uu = bid + k * G;
     if (uu < units) {
       const int f = uu / NBAND;
       const int view = f >= a.n ? 1 : 0, fb = f - view * a.n;
@@ -166,7 +179,7 @@ __global__ __launch_bounds__(NTHR, 2 * NTHR / 256) void conv1_aug_kernel(Conv1Au
     float shx, shy;
   };
   auto make_unit = [&](int k) {
-    const int u = blockIdx.x + k * G;
+    const int u = bid + k * G;
     Unit q;
     q.f = u / NBAND;
     const int band = u - q.f * NBAND;
@@ -203,7 +216,7 @@ __global__ __launch_bounds__(NTHR, 2 * NTHR / 256) void conv1_aug_kernel(Conv1Au
     }
   };
 
-  const int nmine = blockIdx.x < units ? (units - 1 - (int)blockIdx.x) / G + 1 : 0;
+  const int nmine = bid < units ? (units - 1 - bid) / G + 1 : 0;
   Unit cur{};
   if (nmine > 0) {
     cur = make_unit(0);
@@ -408,14 +421,23 @@ extern "C" DRQ_API void drq_dev_conv1aug_stamps(void* p) { g_conv1aug_stamps = (
 // bf_mma != 0: the layer's products on the bf16 MFMA (the bf16 update path; internal and drq_conv1_aug_fwd_bf16)
 int drq_conv1_aug_fwd_any(int bf_mma, const uint8_t* obs, const float* shift, const uint8_t* obs1, const float* shift1,
                           const float* base_grid, const float* w, const float* bias, float* xaug, float* y, int n,
-                          int n_store, hipStream_t st) {
+                          int n_store, hipStream_t st, const float* const* wino_w, float* wino_u) {
   if (!obs || !shift || !obs1 || !shift1 || !base_grid || !w || !bias || !y || n <= 0 || n_store < 0 || n_store > 2 * n)
     return DRQ_EARG;
   if (n_store > 0 && !xaug) return DRQ_EARG;
   if (((uintptr_t)obs & 3) || ((uintptr_t)obs1 & 3)) return DRQ_EARG;     // rows are read as dwords
   const size_t yb = (size_t)2 * n * 32 * PO * 4;
   if (yb >= (1ull << 31)) return DRQ_EARG;
-  Conv1AugArgs a{{obs, obs1}, {shift, shift1}, base_grid, w, bias, xaug, y, n, n_store, (unsigned)yb, 1, nullptr};
+  Conv1AugArgs a{};
+  a.obs[0] = obs; a.obs[1] = obs1;
+  a.shift[0] = shift; a.shift[1] = shift1;
+  a.base = base_grid; a.w = w; a.bias = bias; a.xaug = xaug; a.y = y;
+  a.n = n; a.n_store = n_store; a.y_bytes = (unsigned)yb; a.stagger = 1; a.stamps = nullptr;
+  if (wino_w && wino_u) {
+    for (int l = 0; l < 3; ++l) a.wino_w[l] = wino_w[l];
+    a.wino_u = wino_u;
+    a.n_rider = 6;
+  }
 #ifdef DRQ_DEV
   a.stagger = g_conv1aug_stagger;
   a.stamps = g_conv1aug_stamps;
@@ -442,6 +464,7 @@ int drq_conv1_aug_fwd_any(int bf_mma, const uint8_t* obs, const float* shift, co
   const long cap = 2L * drq_num_cus();
   if (blocks > cap) blocks = cap;
   if (blocks * MAXU < units) blocks = (units + MAXU - 1) / MAXU;     // a workgroup's shift table holds MAXU units
+  blocks += a.n_rider;
 #ifdef DRQ_DEV
   {
     static bool said = false;
@@ -479,13 +502,13 @@ extern "C" {
 DRQ_API int drq_conv1_aug_fwd(const uint8_t* obs, const float* shift, const uint8_t* obs1, const float* shift1,
                               const float* base_grid, const float* w, const float* bias, float* xaug, float* y, int n,
                               int n_store, hipStream_t st) {
-  return drq_conv1_aug_fwd_any(0, obs, shift, obs1, shift1, base_grid, w, bias, xaug, y, n, n_store, st);
+  return drq_conv1_aug_fwd_any(0, obs, shift, obs1, shift1, base_grid, w, bias, xaug, y, n, n_store, st, nullptr, nullptr);
 }
 
 DRQ_API int drq_conv1_aug_fwd_bf16(const uint8_t* obs, const float* shift, const uint8_t* obs1, const float* shift1,
                                    const float* base_grid, const float* w, const float* bias, float* xaug, float* y,
                                    int n, int n_store, hipStream_t st) {
-  return drq_conv1_aug_fwd_any(1, obs, shift, obs1, shift1, base_grid, w, bias, xaug, y, n, n_store, st);
+  return drq_conv1_aug_fwd_any(1, obs, shift, obs1, shift1, base_grid, w, bias, xaug, y, n, n_store, st, nullptr, nullptr);
 }
 
 }  // extern "C"

@@ -14,12 +14,14 @@
 // transforms it in registers and feeds the 16 positions.  U = G g G^T is computed once per workgroup into LDS in
 // MFMA-lane order (one ds_read_b64 per position and k-step serves both cout halves).
 #include "common.h"
+#include "wino_u.h"
 
 namespace {
 
 struct WinoArgs {
   const float* x;      // [NB][32][HIN][HIN]
   const float* w;      // canonical [32][32][3][3]
+  const float* pre;    // optional: the U image of (w, wmode) in global memory (wino_u.h), else null
   const float* bias;   // [32] or null
   const float* mask;   // [NB][32][HOUT][HOUT] or null : out *= (mask > 0)
   float* y;
@@ -80,49 +82,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   const int tl = lane & 15;     // tile of the unit (B column / D column)
   const int kk = lane >> 4;     // input channel inside the k-step (A/B k index); D rows 4*kk + r
 
-  // ---- U = G g G^T for the 1024 (cout, cin) filters -> LDS
-  // The canonical weights are copied into LDS first (contiguous global reads; rows of 32 filters at a pitch of 289
-  // floats), every thread then pulls the nine taps of its four filters into registers, and only after a barrier is
-  // the same memory overwritten with U.  Lanes walk the OUTPUT channel: the staging reads are conflict-free in both
-  // gather modes (row pitch 289 / filter pitch 9, both odd) and the U writes land in 32 distinct banks per half-wave
-  // (a lane-ordered gather from global memory costs several us per workgroup, and so did U writes that walked the
-  // input channel: 32 lanes on one bank).
-  constexpr int SP = 289;
-  for (int i = tid; i < 32 * 288; i += 256) U[(i / 288) * SP + (i % 288)] = a.w[i];
-  __syncthreads();
-  float g[4][9];
+  // ---- U = G g G^T for the 1024 (cout, cin) filters -> LDS: a plain copy of the image a rider of conv1_aug_kernel
+  // prepared for this update (a.pre), else computed here (wino_u.h)
+  if (a.pre) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.pre);
+    f32x4* dst = reinterpret_cast<f32x4*>(U);
+    f32x4 v[16];
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int q = it * 256 + tid;
-    const int oc = q & 31, ic = q >> 5;      // output channel (A row) / reduction channel of THIS product
-    const float* src = a.wmode == 0 ? U + oc * SP + ic * 9 : U + ic * SP + oc * 9;
+    for (int i = 0; i < 16; ++i) v[i] = src[i * 256 + tid];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) g[it][t] = src[a.wmode == 0 ? t : 8 - t];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int q = it * 256 + tid;
-    const int oc = q & 31, ic = q >> 5;
-    float tm[4][3];
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const float g0 = g[it][kx], g1 = g[it][3 + kx], g2 = g[it][6 + kx];
-      tm[0][kx] = g0;
-      tm[1][kx] = 0.5f * ((g0 + g2) + g1);
-      tm[2][kx] = 0.5f * ((g0 + g2) - g1);
-      tm[3][kx] = g2;
-    }
-    const int c = ic >> 2, k4 = ic & 3, h = oc >> 4;
-    float* dst = U + ((size_t)c * 64 + k4 * 16 + (oc & 15)) * 2 + h;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float t0 = tm[i][0], t1 = tm[i][1], t2 = tm[i][2];
-      dst[(i * 4 + 0) * (8 * 64 * 2)] = t0;
-      dst[(i * 4 + 1) * (8 * 64 * 2)] = 0.5f * ((t0 + t2) + t1);
-      dst[(i * 4 + 2) * (8 * 64 * 2)] = 0.5f * ((t0 + t2) - t1);
-      dst[(i * 4 + 3) * (8 * 64 * 2)] = t2;
-    }
+    for (int i = 0; i < 16; ++i) dst[i * 256 + tid] = v[i];
+  } else {
+    wino_u_image<true>(a.w, a.wmode, U, U, tid);
   }
   // bias of this lane's eight output channels: cout = 16*h + 4*kk + r
   float bv[2][4];
@@ -379,37 +350,48 @@ extern "C" DRQ_API void drq_dev_wino_stagger(int v) { g_wino_stagger = v; }
 extern "C" DRQ_API void drq_dev_wino_stamps(void* p) { g_wino_stamps = (unsigned long long*)p; }
 #endif
 
-extern "C" {
-
-// Same contract as drq_conv3x3_fwd (conv.hip) for cin = 32, stride 1, in Winograd form (rounding differs).
-DRQ_API int drq_conv3x3_fwd_wino(const float* x, const float* w, const float* bias, float* y, int nb, int hin, int relu,
-                                 long y_bs, long y_cs, long y_rs, long y_off, hipStream_t st) {
+// internal (step.hip): u_image = the layer's U image prepared by conv1_aug_kernel's rider for this update, or null
+int drq_conv3x3_fwd_wino_pre(const float* x, const float* w, const float* u_image, const float* bias, float* y, int nb,
+                             int hin, int relu, long y_bs, long y_cs, long y_rs, long y_off, hipStream_t st) {
   if (!x || !w || !y || nb <= 0) return DRQ_EARG;
   const size_t xb = (size_t)nb * 32 * hin * hin * 4;
   const size_t yb = (size_t)nb * y_bs * 4;
   if (xb >= (1ull << 31) || yb >= (1ull << 31) || y_off < 0 || y_bs <= 0) return DRQ_EARG;
-  WinoArgs a{x, w, bias, nullptr, y, (int)y_bs, (int)y_cs, (int)y_rs, (int)y_off, (unsigned)xb, (unsigned)yb, 0u, nb, relu, 0, 0, nullptr};
+  WinoArgs a{x, w, u_image, bias, nullptr, y, (int)y_bs, (int)y_cs, (int)y_rs, (int)y_off, (unsigned)xb, (unsigned)yb, 0u, nb, relu, 0, 0, nullptr};
   if (hin == 41) return launch_wino<41>(a, st);
   if (hin == 39) return launch_wino<39>(a, st);
   if (hin == 37) return launch_wino<37>(a, st);
   return DRQ_EARG;
 }
 
-// Same contract as drq_conv3x3_dgrad (conv.hip) in Winograd form.
-DRQ_API int drq_conv3x3_dgrad_wino(const float* dy_pad, const float* w, const float* mask, float* dx, int nb, int hout,
-                                   long dx_bs, long dx_cs, long dx_rs, long dx_off, hipStream_t st) {
+int drq_conv3x3_dgrad_wino_pre(const float* dy_pad, const float* w, const float* u_image, const float* mask, float* dx,
+                               int nb, int hout, long dx_bs, long dx_cs, long dx_rs, long dx_off, hipStream_t st) {
   if (!dy_pad || !w || !dx || nb <= 0) return DRQ_EARG;
   const int hp = hout + 4;
   const size_t xb = (size_t)nb * 32 * hp * hp * 4;
   const size_t yb = (size_t)nb * dx_bs * 4;
   const size_t mb = (size_t)nb * 32 * (hout + 2) * (hout + 2) * 4;
   if (xb >= (1ull << 31) || yb >= (1ull << 31) || dx_off < 0 || dx_bs <= 0) return DRQ_EARG;
-  WinoArgs a{dy_pad, w, nullptr, mask, dx, (int)dx_bs, (int)dx_cs, (int)dx_rs, (int)dx_off, (unsigned)xb, (unsigned)yb,
+  WinoArgs a{dy_pad, w, u_image, nullptr, mask, dx, (int)dx_bs, (int)dx_cs, (int)dx_rs, (int)dx_off, (unsigned)xb, (unsigned)yb,
              (unsigned)mb, nb, 0, 1, 0, nullptr};
   if (hp == 39) return launch_wino<39>(a, st);
   if (hp == 41) return launch_wino<41>(a, st);
   if (hp == 43) return launch_wino<43>(a, st);
   return DRQ_EARG;
+}
+
+extern "C" {
+
+// Same contract as drq_conv3x3_fwd (conv.hip) for cin = 32, stride 1, in Winograd form (rounding differs).
+DRQ_API int drq_conv3x3_fwd_wino(const float* x, const float* w, const float* bias, float* y, int nb, int hin, int relu,
+                                 long y_bs, long y_cs, long y_rs, long y_off, hipStream_t st) {
+  return drq_conv3x3_fwd_wino_pre(x, w, nullptr, bias, y, nb, hin, relu, y_bs, y_cs, y_rs, y_off, st);
+}
+
+// Same contract as drq_conv3x3_dgrad (conv.hip) in Winograd form.
+DRQ_API int drq_conv3x3_dgrad_wino(const float* dy_pad, const float* w, const float* mask, float* dx, int nb, int hout,
+                                   long dx_bs, long dx_cs, long dx_rs, long dx_off, hipStream_t st) {
+  return drq_conv3x3_dgrad_wino_pre(dy_pad, w, nullptr, mask, dx, nb, hout, dx_bs, dx_cs, dx_rs, dx_off, st);
 }
 
 }  // extern "C"

@@ -47,7 +47,12 @@ int drq_gemm_batched_partial_any(int bf16, int nbatch, const float* const* A, lo
 // conv1aug.hip (internal): bf_mma selects the bf16-MFMA form of the layer's products
 int drq_conv1_aug_fwd_any(int bf_mma, const uint8_t* obs, const float* shift, const uint8_t* obs1, const float* shift1,
                           const float* base_grid, const float* w, const float* bias, float* xaug, float* y, int n,
-                          int n_store, hipStream_t st);
+                          int n_store, hipStream_t st, const float* const* wino_w, float* wino_u);
+// conv_wino.hip (internal): the Winograd kernels with the layer's U image prepared by conv1_aug_kernel's rider
+int drq_conv3x3_fwd_wino_pre(const float* x, const float* w, const float* u_image, const float* bias, float* y, int nb,
+                             int hin, int relu, long y_bs, long y_cs, long y_rs, long y_off, hipStream_t st);
+int drq_conv3x3_dgrad_wino_pre(const float* dy_pad, const float* w, const float* u_image, const float* mask, float* dx,
+                               int nb, int hout, long dx_bs, long dx_cs, long dx_rs, long dx_off, hipStream_t st);
 // gemm2.hip (internal): the trunk weight gradient with the LayerNorm parameter gradients riding in the same launch
 int drq_trunk_wgrad_ln(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K,
                        float* rowsum, const float* ln_dln, const float* ln_xhat, float* ln_dgamma, float* ln_dbeta,
@@ -153,7 +158,9 @@ enum {
   W_HROWS, W_P3, W_Z4,                            // actor trunk output / policy output over 2B rows
   W_T1, W_T2,                                     // target-Q hidden activations, reused by the actor step
   W_DC2, W_DC1, W_DHA, W_DLN, W_DPRE, W_DP2, W_DP1, W_DH_A, W_DA,
-  W_GEMM_WS, W_CONV_WS, W_COUNT
+  W_GEMM_WS, W_CONV_WS,
+  W_WINO_U,                                       // six Winograd weight images of the update: [layer 2..4][fwd, dgrad][16384]
+  W_COUNT
 };
 
 WsLayout ws_layout(int B, int C, int A, int F, int H) {
@@ -213,6 +220,7 @@ WsLayout ws_layout(int B, int C, int A, int F, int H) {
   // H x H weight gradients; 64 MiB covers every shape the step issues (checked per call).
   take(W_GEMM_WS, 16L * 1024 * 1024);
   take(W_CONV_WS, (long)(drq_conv3x3_wgrad_ws_bytes() / sizeof(float)));
+  take(W_WINO_U, 6L * 16384);
   w.total = off;
   return w;
 }
@@ -300,9 +308,11 @@ int encoder_forward(const Ctx& c, const float* x, int nb, float* a1, float* a2, 
     if (c.bf16() && l > 0)
       CK(drq_conv3x3_fwd_bf16(in, c.p(P.enc_w[l]), c.p(P.enc_b[l]), outs[l], nb, hin, 1, 32L * hout * hout,
                               (long)hout * hout, hout, 0, c.st));
-    else if (l > 0)   // the 32->32 layers in Winograd F(2x2,3x3) form (conv_wino.hip)
-      CK(drq_conv3x3_fwd_wino(in, c.p(P.enc_w[l]), c.p(P.enc_b[l]), outs[l], nb, hin, 1, 32L * hout * hout,
-                              (long)hout * hout, hout, 0, c.st));
+    else if (l > 0)   // the 32->32 layers in Winograd F(2x2,3x3) form (conv_wino.hip); in the update (x == nullptr) the
+                      // weight images come from the riders of the fused aug+conv1 launch
+      CK(drq_conv3x3_fwd_wino_pre(in, c.p(P.enc_w[l]), x ? nullptr : c.ws(W_WINO_U) + (2L * (l - 1)) * 16384,
+                                  c.p(P.enc_b[l]), outs[l], nb, hin, 1, 32L * hout * hout, (long)hout * hout, hout, 0,
+                                  c.st));
     else
     CK(drq_conv3x3_fwd(in, c.p(P.enc_w[l]), c.p(P.enc_b[l]), outs[l], nb, l == 0 ? c.s->C : 32, hin, l == 0 ? 2 : 1,
                        1, 32L * hout * hout, (long)hout * hout, hout, 0, c.st));
@@ -380,8 +390,11 @@ int phase_encode(const Ctx& c) {
   // aug (drqv2.py:241-242) + /255-0.5 (:64) + conv1 (:55) in one kernel that reads the uint8 frames once; rows
   // [0,B) = obs, [B,2B) = next_obs.  Only the obs view's encoder input is kept (conv1's weight gradient reads it).
   (void)C;
+  // riders of the same launch: the Winograd images of the conv2..4 weights for this update's forward and backward
+  const float* wino_w[3] = {c.p(c.P.enc_w[1]), c.p(c.P.enc_w[2]), c.p(c.P.enc_w[3])};
   CK(drq_conv1_aug_fwd_any(c.bf16(), s->obs, s->shift_obs, s->next_obs, s->shift_next, s->base_grid,
-                           c.p(c.P.enc_w[0]), c.p(c.P.enc_b[0]), aug, c.ws(W_ACT1), B, s->store_aug_next ? 2 * B : B, st));
+                           c.p(c.P.enc_w[0]), c.p(c.P.enc_b[0]), aug, c.ws(W_ACT1), B, s->store_aug_next ? 2 * B : B, st,
+                           c.bf16() ? nullptr : wino_w, c.bf16() ? nullptr : c.ws(W_WINO_U)));
   // layers 2..4 on both views in one pass (:244-246)
   CK(encoder_forward(c, nullptr, 2 * B, c.ws(W_ACT1), c.ws(W_ACT2), c.ws(W_ACT3), c.ws(W_FEAT), true));
   return 0;
@@ -537,8 +550,8 @@ int phase_conv_backward(const Ctx& c) {
         CK(drq_conv3x3_dgrad_bf16(dy, c.p(P.enc_w[l]), c.ws(actid[l]), c.ws(dyid[l - 1]), B, hout, 32L * hpi * hpi,
                                   (long)hpi * hpi, hpi, 2L * hpi + 2, st));
       else
-      CK(drq_conv3x3_dgrad_wino(dy, c.p(P.enc_w[l]), c.ws(actid[l]), c.ws(dyid[l - 1]), B, hout, 32L * hpi * hpi,
-                                (long)hpi * hpi, hpi, 2L * hpi + 2, st));
+      CK(drq_conv3x3_dgrad_wino_pre(dy, c.p(P.enc_w[l]), c.ws(W_WINO_U) + (2L * (l - 1) + 1) * 16384, c.ws(actid[l]),
+                                    c.ws(dyid[l - 1]), B, hout, 32L * hpi * hpi, (long)hpi * hpi, hpi, 2L * hpi + 2, st));
       if (ev && l == 2 && hipEventRecord((hipEvent_t)ev[3], st) != hipSuccess) return DRQ_EARG;
     }
   }
