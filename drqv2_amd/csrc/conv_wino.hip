@@ -166,7 +166,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   }
   for (; unit < nunit; unit += nwave) {
     const int nvoff = patch_voff(unit + nwave < nunit ? unit + nwave : unit);
+    // where this unit's outputs (and the mask) live
+    const int t0 = unit * 16 + tl;
+    const bool valid = t0 < ntile;
+    const int t = valid ? t0 : ntile - 1;
+    const int b = t / TT, rem = t - b * TT;
+    const int ty = rem / TH, tx = rem - ty * TH;
+    const bool c1ok = 2 * tx + 1 < HOUT, r1ok = 2 * ty + 1 < HOUT;
+    const int ybase = (a.y_off + b * a.y_bs + (4 * kk) * a.y_cs + (2 * ty) * a.y_rs + 2 * tx) * 4;
+    const int mbase = (((b * 32 + 4 * kk) * HOUT + 2 * ty) * HOUT + 2 * tx) * 4;
+    // per-lane store offsets of the unit: [row][8-byte pair | lone first column of the last tile of a row]
+    // (invalid -> beyond num_records: the buffer unit drops the store; no branches in the epilogue)
+    int o64[2], o32[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool rowok = valid && (i == 0 || r1ok);
+      o64[i] = (rowok && c1ok) ? ybase : kDrop;
+      o32[i] = (rowok && !c1ok) ? ybase : kDrop;
+    }
     f32x4 acc[16][2];
+    u32x2w mk[2][4][2];                      // the ReLU mask of the layer below (MASK)
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       // Every k-step is pinned into the same issue order (sched_barrier): the patch of the NEXT step and the A
@@ -222,44 +241,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
       half_step(A0, 0);
       __builtin_amdgcn_sched_barrier(0);
       load_A(A0, (c + 1) & 7, 0);            // the next k-step's (or the next unit's first) lower half
+      if constexpr (MASK) {
+        if (c == 7) {                        // the first half of the mask flies under the unit's last sixteen MFMAs
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+              mk[0][r][i] = __builtin_amdgcn_raw_buffer_load_b64(mrs, mbase + i * (HOUT * 4), r * (HOUT * HOUT * 4), 0);
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
       half_step(A1, 1);
       __builtin_amdgcn_sched_barrier(0);
     }
     // ---- output transform Y = A^T M A, bias, ReLU / mask, stores
     {
-      const int t0 = unit * 16 + tl;
-      const bool valid = t0 < ntile;
-      const int t = valid ? t0 : ntile - 1;
-      const int b = t / TT, rem = t - b * TT;
-      const int ty = rem / TH, tx = rem - ty * TH;
-      const bool c1ok = 2 * tx + 1 < HOUT, r1ok = 2 * ty + 1 < HOUT;
-      const int ybase = (a.y_off + b * a.y_bs + (4 * kk) * a.y_cs + (2 * ty) * a.y_rs + 2 * tx) * 4;
-      const int mbase = (((b * 32 + 4 * kk) * HOUT + 2 * ty) * HOUT + 2 * tx) * 4;
-      // per-lane store offsets of the unit: [row][8-byte pair | lone first column of the last tile of a row]
-      // (invalid -> beyond num_records: the buffer unit drops the store; no branches in the epilogue)
-      int o64[2], o32[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const bool rowok = valid && (i == 0 || r1ok);
-        o64[i] = (rowok && c1ok) ? ybase : kDrop;
-        o32[i] = (rowok && !c1ok) ? ybase : kDrop;
-      }
       if constexpr (ABL & 2) {               // every accumulator stays live although only four are stored
 #pragma unroll
         for (int pos = 0; pos < 16; ++pos) asm volatile("" ::"v"(acc[pos][0]), "v"(acc[pos][1]));
       }
-      // the ReLU mask of the layer below: all 16 loads go out before the transform arithmetic
-      u32x2w mk[2][4][2];
-      if constexpr (MASK) {
+      if constexpr (MASK) {                  // ... the second half under the first half's transform arithmetic
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-              mk[h][r][i] = __builtin_amdgcn_raw_buffer_load_b64(mrs, mbase + i * (HOUT * 4),
-                                                                 (16 * h + r) * (HOUT * HOUT * 4), 0);
+          for (int i = 0; i < 2; ++i)
+            mk[1][r][i] = __builtin_amdgcn_raw_buffer_load_b64(mrs, mbase + i * (HOUT * 4), (16 + r) * (HOUT * HOUT * 4), 0);
         __builtin_amdgcn_sched_barrier(0);
       }
       const int ycs4 = a.y_cs * 4, yrs4 = a.y_rs * 4;
