@@ -191,6 +191,9 @@ class DrQV2Agent:
         if self._draw_hook is not None:
             return self._draw_hook(n_global, A)
         dev = self.device
+        fused = self._engine.rng_draws(n_global, A, 2 * self.aug.pad + 1)           # the same four draws, one launch
+        if fused is not None:
+            return fused
         sh_o = self.aug.draw(n_global, dev)                                        # RNG draw 1 (drqv2.py:241)
         sh_n = self.aug.draw(n_global, dev)                                        # RNG draw 2 (:242)
         n_c = _standard_normal((n_global, A), dtype=torch.float32, device=dev)     # draw 3 (:183)

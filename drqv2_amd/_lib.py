@@ -80,6 +80,7 @@ PROTOTYPES = {
     "drq_update_phase": (I, [C.POINTER(DrqStep), I]),
     "drq_act_forward": (I, [C.POINTER(DrqStep), P, I, P]),
     "drq_publish_sums": (I, [P, P, C.c_uint, P]),
+    "drq_rng_draws": (I, [C.c_uint64, C.c_uint64, I, I, I, P, P, P, P, P]),
 }
 
 WS_IDS = ["AUG", "ACT1", "ACT2", "ACT3", "FEAT", "Z_NEXT", "Z_OBS", "HA_T", "HA_C", "H_AN", "H_AO", "Q", "TQ",
@@ -110,7 +111,7 @@ def load(dev=False):
         fn = getattr(lib, name)       # AttributeError = ABI mismatch, also loud
         fn.restype = res
         fn.argtypes = args
-    if lib.drq_abi_version() != 5:
+    if lib.drq_abi_version() != 6:
         raise DrqError("libdrqv2_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

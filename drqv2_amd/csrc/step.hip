@@ -711,7 +711,7 @@ int check_step(const DrqStep* s) {
 
 extern "C" {
 
-DRQ_API int drq_abi_version(void) { return 5; }
+DRQ_API int drq_abi_version(void) { return 6; }
 
 DRQ_API int drq_param_layout(int C, int A, int F, int H, long* out, int cap) {
   if (!out || cap < DRQ_PARAM_LAYOUT_LEN || C <= 0 || A <= 0 || F <= 0 || H <= 0) return DRQ_EARG;

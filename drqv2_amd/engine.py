@@ -245,6 +245,9 @@ class StepEngine:
         self.world = 1
         self.rank = 0
         self.exchange = None      # GradExchange (enable_data_parallel)
+        self.fused_rng = True     # the update's four draws in one launch (rng_draws); None/False: torch's own four calls
+        self._rng_ok = None       # verdict of _rng_selftest
+        self._rng_bufs = None
 
     # ---- arenas --------------------------------------------------------------------------
     def _adopt(self, name, mod):
@@ -320,6 +323,62 @@ class StepEngine:
             return
         arr = (ctypes.c_void_p * 4)(*[int(e.cuda_event) for e in events])
         self._timing_array = arr
+
+    # ---- the update's random draws ----------------------------------------------------------
+    def _rng_launch(self, gen, n, A, pad_range, with_noise):
+        """One launch for the draws, from the generator's current (seed, offset); advances the offset like the ATen
+        launches it replaces.  Returns (shift_obs [n,1,1,2], shift_next, noise_critic [n,A], noise_actor)."""
+        key = (n, A)
+        if self._rng_bufs is None or self._rng_bufs[0] != key:
+            mk = lambda *sh: torch.empty(sh, device=self.device, dtype=torch.float32)
+            self._rng_bufs = (key, (mk(n, 1, 1, 2), mk(n, 1, 1, 2), mk(n, A), mk(n, A)))
+        bufs = self._rng_bufs[1]
+        seed, off = gen.initial_seed(), gen.get_offset()
+        with torch.cuda.device(self.device):
+            check(_lib.load().drq_rng_draws(seed, off, 2 * n, n * A if with_noise else 0, pad_range,
+                                            *(ptr(b) for b in bufs), self._stream()), "drq_rng_draws")
+        gen.set_offset(off + (16 if with_noise else 8))
+        if not with_noise:                              # torch's own normal_ calls, in the reference's order
+            bufs[2].normal_()
+            bufs[3].normal_()
+        return bufs
+
+    def _rng_selftest(self, gen, n, A, pad_range):
+        """Once per engine: what the fused launch reproduces of torch's own four calls, bit for bit, from the same
+        generator state (the stream contract of SURVEY App. C).  "all": the four draws in one launch; "shifts": the
+        two integer draws (exact by construction) in one launch, torch's normal_ for the noises -- the normal draws go
+        through logf / sincosf, and a torch built against another device-library release rounds their last bit
+        differently; None: torch's own calls for everything."""
+        from torch.distributions.utils import _standard_normal
+        state = gen.get_state()
+        ref = [torch.randint(0, pad_range, size=(n, 1, 1, 2), device=self.device, dtype=torch.float32) for _ in range(2)]
+        ref += [_standard_normal((n, A), dtype=torch.float32, device=self.device) for _ in range(2)]
+        end_off = gen.get_offset()
+        verdict = None
+        for mode in ("all", "shifts"):
+            gen.set_state(state)
+            try:
+                got = [t.clone() for t in self._rng_launch(gen, n, A, pad_range, mode == "all")]
+            except _lib.DrqError:
+                break
+            if gen.get_offset() == end_off and all(torch.equal(a.view(-1), b.view(-1)) for a, b in zip(ref, got)):
+                verdict = mode
+                break
+        gen.set_state(state)
+        return verdict
+
+    def rng_draws(self, n, A, pad_range):
+        """The four draws of an update in the reference's order from torch's default generator of this device with
+        fewer launches -- or None when that path is off, refused the size, or failed its self test (the caller then
+        issues torch's own four calls).  The returned tensors are reused by the next update."""
+        if not self.fused_rng or self.device.type != "cuda" or 2 * n > 65536 or n * A > 65536:
+            return None
+        gen = torch.cuda.default_generators[self.device.index]
+        if self._rng_ok is None:
+            self._rng_ok = self._rng_selftest(gen, n, A, pad_range) or False
+        if not self._rng_ok:
+            return None
+        return self._rng_launch(gen, n, A, pad_range, self._rng_ok == "all")
 
     def _side_stream(self):
         if self._side is None:

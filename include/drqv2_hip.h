@@ -183,6 +183,15 @@ int drq_nstep_gather(const uint8_t* frames, const float* action, const float* re
                      float* act_out, float* rew_out, float* disc_out, uint8_t* next_obs, drq_stream_t stream);
 int drq_tanh(const float* x, float* y, long n, drq_stream_t stream);
 
+/* ---- the four random draws of one update in one launch, bit-identical to the ATen launches of the reference's calls
+ * (torch.randint(0, range, (B,1,1,2), dtype=float32) x2 from drqv2.py:34,241-242; torch.empty((B,A)).normal_() x2 from
+ * utils.py:135 via drqv2.py:183,211): Philox4x32-10, key = seed, subsequence = element index, offsets offset + 0, 4, 8,
+ * 12.  (seed, offset) = torch's CUDA generator state before the draws; the caller advances its offset by 16.
+ * n_shift = 2*B, n_noise = B*A, each <= 65536 (else DRQ_EARG: ATen's launch geometry differs there).  n_noise = 0: the
+ * two shift draws only (offsets + 0, 4; the caller advances by 8 and draws the noises itself). */
+int drq_rng_draws(unsigned long long seed, unsigned long long offset, int n_shift, int n_noise, int range,
+                  float* shift_obs, float* shift_next, float* noise_critic, float* noise_actor, drq_stream_t stream);
+
 /* ---- whole-step entry: DrQV2Agent.update (drqv2.py:230-262) ------------------------------------ */
 typedef struct {
   int B, global_B, C, A, F, H;

@@ -351,6 +351,7 @@ def test_rng_draw_order_matches_reference():
     with open(os.path.join(G, "interface.json")) as f:
         trace_ref = json.load(f)["rng_trace"]
     ag = make_agent(cfg)
+    ag._engine.fused_rng = False          # the path that issues torch's own four calls (the fused launch: next test)
     calls = []
     import drqv2
     real_randint, real_sn = torch.randint, drqv2._standard_normal
@@ -379,6 +380,51 @@ def test_rng_draw_order_matches_reference():
     torch.manual_seed(5)
     b = torch.randint(0, 9, size=(16, 1, 1, 2), device="cuda", dtype=torch.float32)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n,A", [(4, 3), (32, 1), (256, 6), (512, 12), (256, 21), (2048, 21), (100, 7)])
+def test_fused_rng_launch_equals_the_four_torch_calls(n, A):
+    """drq_rng_draws (one launch for the draws it can reproduce: all four, or the two integer shift draws when this
+    torch build rounds logf / sincosf differently from the local device libraries) against the reference's own calls
+    on the same generator state: the same shifts and noises bit for bit, the same generator offset afterwards, the
+    same next random number -- a run with the fused launch consumes torch's RNG stream exactly like the reference
+    (SURVEY App. C)."""
+    import drqv2
+    from torch.distributions.utils import _standard_normal
+    ag = make_agent(CASES["small_h64_b6"])
+    eng = ag._engine
+    gen = torch.cuda.default_generators[eng.device.index]
+    torch.manual_seed(1234 + n + A)
+    torch.rand(3, device="cuda")                       # a generator that is not at offset 0
+    st = gen.get_state()
+    ref = [torch.randint(0, 9, size=(n, 1, 1, 2), device="cuda", dtype=torch.float32) for _ in range(2)]
+    ref += [_standard_normal((n, A), dtype=torch.float32, device="cuda") for _ in range(2)]
+    after_ref = torch.rand(5, device="cuda")
+    gen.set_state(st)
+    got = eng.rng_draws(n, A, 9)
+    assert got is not None and eng._rng_ok in ("all", "shifts")
+    got = [t.clone() for t in got]
+    after_got = torch.rand(5, device="cuda")
+    for a, b in zip(ref, got):
+        assert a.shape == b.shape and torch.equal(a, b)
+    assert torch.equal(after_ref, after_got)
+    assert float(ref[0].min()) >= 0 and float(ref[0].max()) <= 8
+
+
+def test_update_is_identical_with_and_without_the_fused_rng_launch():
+    cfg = CASES["small_h64_b6"]
+    outs = []
+    for fused in (True, False):
+        ag = make_agent(cfg)
+        ag._engine.fused_rng = fused
+        torch.manual_seed(77)
+        ms = []
+        for u in range(3):
+            batch = synth.make_batch(cfg["B"], cfg["A"], cfg["C"], seed=u)
+            ms.append(ag.update(iter([tuple(x.numpy() for x in batch)]), 2 * u))
+        outs.append((ms, ag._engine.params.clone(), torch.rand(4, device="cuda")))
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
 
 
 def test_act_matches_oracle():
