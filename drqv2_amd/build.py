@@ -56,7 +56,8 @@ def build(force=False, verbose=True, dev=False):
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed for {obj}")
         objs.append(obj)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
+    # -z defs: an internal entry point declared with the wrong linkage fails here, not at dlopen on the GPU box
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-z,defs", "-o", lib] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

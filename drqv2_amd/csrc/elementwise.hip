@@ -688,10 +688,18 @@ struct QOutBwdArgs {
   int B, H;
   // optional fused TD loss (drqv2.py:185-189, two heads: z = 0, 1): dq is not given but computed per row from the
   // Q values; workgroup (0, 0) also leaves sums[0..4] like td_loss_kernel
+  // td == 2: the actor loss instead (drqv2.py:212-216, actor_loss_kernel's arithmetic): dq routed to the smaller head,
+  // ties split; workgroup (0, 0) leaves sums[5..6] and publishes all eight sums to the host mirror when one is given
   int td;
   const float *tq1, *tq2, *q1, *q2, *reward, *discount;
   float invB;
   float* sums;
+  const float *act, *mu;   // td == 2: the sampled action [B][lda] and its mean [B][A]
+  long lda;
+  int A;
+  float std;
+  float* sums_host;
+  unsigned seq;
 };
 
 // Workgroup = 64 columns x 16 row groups (1024 threads).  The per-row scalars dq[B] go to LDS once; the only global
@@ -708,7 +716,14 @@ __global__ __launch_bounds__(1024) void qout_bwd_kernel(QOutBwdArgs a) {
   const float* h = a.h[z];
   float* dh = a.dh[z];
   const float wn = a.w[z][nc];
-  if (a.td) {
+  if (a.td == 2) {
+    const float *qz = z == 0 ? a.q1 : a.q2, *qo = z == 0 ? a.q2 : a.q1;
+    const float g = -a.invB;
+    for (int m = threadIdx.x; m < a.B; m += 1024) {
+      const float x = qz[m], y = qo[m];
+      dql[m] = x < y ? g : (x == y ? 0.5f * g : 0.f);
+    }
+  } else if (a.td) {
     const float* qz = z == 0 ? a.q1 : a.q2;
     for (int m = threadIdx.x; m < a.B; m += 1024) {
       const float y = a.reward[m] + a.discount[m] * fminf(a.tq1[m], a.tq2[m]);
@@ -752,8 +767,46 @@ __global__ __launch_bounds__(1024) void qout_bwd_kernel(QOutBwdArgs a) {
       a.db[z][0] = t;
     }
   }
+  // metric sums of the actor loss: workgroup (0, 0), the same fixed tree; then the host mirror
+  if (a.td == 2 && blockIdx.x == 0 && z == 0) {
+    __syncthreads();
+    float v[2] = {0.f, 0.f};
+    const float log_std = logf(a.std);
+    const float c0 = 0.91893853320467274178f;   // log(sqrt(2*pi))
+    const float var2 = 2.f * a.std * a.std;
+    for (int m = threadIdx.x; m < a.B; m += 1024) {
+      v[0] += -fminf(a.q1[m], a.q2[m]);
+      float lp = 0.f;
+      for (int j = 0; j < a.A; ++j) {
+        const float d = a.act[(long)m * a.lda + j] - a.mu[m * a.A + j];
+        lp += -(d * d) / var2 - log_std - c0;
+      }
+      v[1] += lp;
+    }
+    s[threadIdx.x] = v[0];
+    s[1024 + threadIdx.x] = v[1];
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) {
+        s[threadIdx.x] += s[threadIdx.x + o];
+        s[1024 + threadIdx.x] += s[1024 + threadIdx.x + o];
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      const float s5 = s[0], s6 = s[1024];
+      a.sums[5] = s5;
+      a.sums[6] = s6;
+      if (a.sums_host) {   // metrics mirror (DrqStep.sums_host): all eight sums, then the sequence word
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a.sums_host[i] = i == 5 ? s5 : (i == 6 ? s6 : a.sums[i]);
+        __threadfence_system();
+        __hip_atomic_store((unsigned*)(a.sums_host + 8), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
   // metric sums of the TD loss: workgroup (0, 0), per-thread partials over rows tid, tid+1024, ... then a fixed tree
-  if (a.td && blockIdx.x == 0 && z == 0) {
+  if (a.td == 1 && blockIdx.x == 0 && z == 0) {
     __syncthreads();
     float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     for (int m = threadIdx.x; m < a.B; m += 1024) {
@@ -1188,6 +1241,27 @@ int drq_qout_bwd_td(const float* tq1, const float* tq2, const float* q1, const f
   a.td = 1; a.tq1 = tq1; a.tq2 = tq2; a.q1 = q1; a.q2 = q2; a.reward = reward; a.discount = discount;
   a.invB = inv_global_B; a.sums = sums;
   const size_t lds = ((size_t)B + 5 * 1024 + 16) * sizeof(float);      // the sums tree of workgroup (0,0) needs 5 x 1024
+  if (lds > 60 * 1024) return DRQ_EARG;
+  hipLaunchKernelGGL(qout_bwd_kernel, dim3((H + 63) / 64, 2), dim3(1024), lds, st, a);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
+// internal (step.hip, single-GPU schedule): the same backward (input gradient only) with the actor loss (drq_actor_loss)
+// computed inside it: sums[5..6] and the host mirror are written by workgroup (0, 0) of this launch
+int drq_qout_bwd_actor(const float* q1, const float* q2, const float* act, long lda, const float* mu, float std, int A,
+                       float inv_global_B, float* sums, float* sums_host, unsigned seq, const float* const* h,
+                       const float* const* w, float* const* dh, int B, int H, hipStream_t st) {
+  if (!q1 || !q2 || !act || !mu || !sums || !h || !w || !dh || B <= 0 || H <= 0 || A <= 0) return DRQ_EARG;
+  QOutBwdArgs a{};
+  for (int z = 0; z < 2; ++z) {
+    if (!h[z] || !w[z] || !dh[z]) return DRQ_EARG;
+    a.h[z] = h[z]; a.w[z] = w[z]; a.dh[z] = dh[z];
+  }
+  a.B = B; a.H = H;
+  a.td = 2; a.q1 = q1; a.q2 = q2; a.invB = inv_global_B; a.sums = sums;
+  a.act = act; a.lda = lda; a.mu = mu; a.A = A; a.std = std; a.sums_host = sums_host; a.seq = seq;
+  const size_t lds = ((size_t)B + 5 * 1024 + 16) * sizeof(float);
   if (lds > 60 * 1024) return DRQ_EARG;
   hipLaunchKernelGGL(qout_bwd_kernel, dim3((H + 63) / 64, 2), dim3(1024), lds, st, a);
   DRQ_LAUNCH_CHECK();

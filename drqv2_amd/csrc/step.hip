@@ -15,6 +15,10 @@ extern "C" int drq_qout_bwd_td(const float* tq1, const float* tq2, const float* 
                                const float* discount, float inv_global_B, float* sums, const float* const* h,
                                const float* const* w, float* const* dh, float* const* dw, float* const* db, int B,
                                int H, hipStream_t st);
+extern "C" int drq_qout_bwd_actor(const float* q1, const float* q2, const float* act, long lda, const float* mu, float std,
+                                    int A, float inv_global_B, float* sums, float* sums_host, unsigned seq,
+                                    const float* const* h, const float* const* w, float* const* dh, int B, int H,
+                                    hipStream_t st);
 extern "C" int drq_policy_out_fwd(const float* h2, const float* w, const float* b, float* p3, int rows, int H, int A,
                                   const float* noise, float std, float clip, int use_clip, int srow0, float* mu_out,
                                   float* a_out, long lda_out, const float* noise0, float* mu_out0, float* a_out0,
@@ -236,6 +240,13 @@ struct Ctx {
   ParamLayout P;
   WsLayout W;
   hipStream_t st;
+  // phases 6 and 7 issued back to back by one call (single-GPU schedule): the actor loss then rides in the first
+  // launch of the backward (drq_qout_bwd_actor) instead of a launch of its own.  A host that exchanges the metric
+  // sums between the two phases calls them separately and keeps the separate loss launch.
+  bool fuse_actor_loss = false;
+  bool actor_loss_fused() const {
+    return fuse_actor_loss && ((size_t)s->B + 5 * 1024 + 16) * 4 <= 60 * 1024;
+  }
   float* ws(int id) const { return s->ws + W.off[id]; }
   float* p(long off) const { return s->params + off; }
   float* g(long off) const { return s->grads + off; }
@@ -612,8 +623,9 @@ int phase_actor_forward(const Ctx& c) {
   }
   const float invB = 1.0f / (float)s->global_B;
   // the loss kernel also publishes the eight sums to the host mirror when one is given
-  CK(drq_actor_loss_ex(c.ws(W_TQ), c.ws(W_TQ) + B, c.ws(W_HA_C2) + F, FA, c.ws(W_MU_O), s->std, c.ws(W_DQ),
-                       c.ws(W_DQ) + B, s->sums, B, A, invB, s->sums_host, (unsigned)s->step_actor, st));
+  if (!c.actor_loss_fused())
+    CK(drq_actor_loss_ex(c.ws(W_TQ), c.ws(W_TQ) + B, c.ws(W_HA_C2) + F, FA, c.ws(W_MU_O), s->std, c.ws(W_DQ),
+                         c.ws(W_DQ) + B, s->sums, B, A, invB, s->sums_host, (unsigned)s->step_actor, st));
   return 0;
 }
 
@@ -639,7 +651,12 @@ int phase_actor_backward(const Ctx& c) {
     const float *w0a[2] = {c.p(cr.w[0][0]) + F, c.p(cr.w[1][0]) + F}, *w1[2] = {c.p(cr.w[0][1]), c.p(cr.w[1][1])},
                 *w2[2] = {c.p(cr.w[0][2]), c.p(cr.w[1][2])};
     float* da[2] = {c.ws(W_DA), c.ws(W_DA) + (long)B * A};
-    CK(drq_qout_bwd(2, dq, t2, w2, dc2, nullptr, nullptr, B, H, st));
+    if (c.actor_loss_fused())
+      CK(drq_qout_bwd_actor(c.ws(W_TQ), c.ws(W_TQ) + B, c.ws(W_HA_C2) + F, FA, c.ws(W_MU_O), s->std, A,
+                            1.0f / (float)s->global_B, s->sums, s->sums_host, (unsigned)s->step_actor, t2, w2, dc2, B, H,
+                            st));
+    else
+      CK(drq_qout_bwd(2, dq, t2, w2, dc2, nullptr, nullptr, B, H, st));
     CK(c.dgrad(2, dc2c, H, w1, H, dc1, H, B, H, H, t1, H));
     // action columns of layer 1 only; with the fused output-layer backward the split-K partials stay in the
     // workspace and that kernel sums them
@@ -740,6 +757,7 @@ DRQ_API int drq_update_phase(const DrqStep* s, int phase) {
     return DRQ_EARG;
   Ctx c{s, param_layout(s->C, s->A, s->F, s->H), ws_layout(s->B, s->C, s->A, s->F, s->H), (hipStream_t)s->stream};
   if (phase < -1 || phase > 9) return DRQ_EARG;
+  c.fuse_actor_loss = phase == -1 || phase == 1;
   if (phase == 3 || phase == 0 || phase == -1) CK(phase_encode(c));
   if (phase == 4 || phase == 0 || phase == -1) CK(phase_critic_heads(c));
   if (phase == 5 || phase == 0 || phase == -1) CK(phase_conv_backward(c));
