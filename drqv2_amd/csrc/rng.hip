@@ -6,8 +6,11 @@
 // Philox4x32-10 with key = the generator's seed, subsequence = i, offset = the generator's offset; for the sizes of
 // an update (numel <= 256 * grid cap) every thread keeps only the FIRST of its four values, and every launch advances
 // the generator's offset by 4.  randint: x % range as float; normal_(0,1): the first of hiprand_normal4's Box-Muller
-// pair products, times 1 plus 0.  The same hipRAND device functions are used here, so the numbers are the same; the
-// host proves it once per process against torch itself before it trusts this path (engine.py: _rng_selftest).
+// pair products, times 1 plus 0.  The same hipRAND device functions are used here; compiled with -ffp-contract=on
+// (build.py) they also round like torch's copy (tools/rng_flags_probe.py: 0 of 65,536 normals differ; hipcc's default
+// contraction mode: 15 % differ in the last bit).  The host still proves it once per engine against torch itself
+// before it trusts this path, and falls back to the two integer draws or to torch's own calls (engine.py:
+// _rng_selftest).
 #include "common.h"
 #include <hiprand/hiprand_kernel.h>
 
