@@ -383,6 +383,7 @@ def roofline_conv(agent, B, it, step):
                                "tiles of 2x2 for 39x39 outputs); the VALU transforms (56 adds per tile and channel) "
                                "share the f32 datapath with the MFMA and are not counted",
             "direct_equiv_tflops": (fl_f + fl_d) / (t_f + t_d) / 1e12,
+            "frac_direct_equiv": (fl_f + fl_d) / (t_f + t_d) / 1e12 / PEAK_FP32_TFLOPS,
             "avg_launch_us": 0.5e6 * (t_f + t_d), "launch_us": {"conv2_fwd_2B": 1e6 * t_f, "conv3_dgrad_B": 1e6 * t_d},
             "executed_gflop_per_launch": {"conv2_fwd_2B": ex_f / 1e9, "conv3_dgrad_B": ex_d / 1e9},
             "alg_gflop_per_launch": {"conv2_fwd_2B": fl_f / 1e9, "conv3_dgrad_B": fl_d / 1e9}, "frames_per_launch": B,
