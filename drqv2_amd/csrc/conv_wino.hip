@@ -15,6 +15,7 @@
 // MFMA-lane order (one ds_read_b64 per position and k-step serves both cout halves).
 #include "common.h"
 #include "wino_u.h"
+#include <type_traits>
 
 namespace {
 
@@ -155,17 +156,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
     for (int p = 0; p < 8; ++p) A[p] = Ul[((8 * g + p) * 8 + c) * 64];
   };
 
-  int unit = blockIdx.x * 4 + wid;
+  // ---- this wave's work.  Units are dealt round-robin: wave gw takes units gw, gw + nwave, ... of the first q rounds.
+  // The r = nunit - q*nwave units left over are cut in HALF-units (16 tiles x one half of the output channels: the
+  // MFMAs of one channel half, the whole input transform) wherever that lowers the busiest SIMD's load: with 2r <=
+  // nwave every left-over unit goes to two neighbouring waves as two halves (a SIMD then carries 2q + 1/2 or 2q + 1
+  // units instead of 2q + 1 or 2q + 2 -- the two workgroups of a CU are blockIdx b and b + 256, so the waves
+  // [0, 1024) sit on distinct SIMDs); with 2r > nwave the first nf = 2r - nwave waves take a whole unit, every other
+  // wave a half.  Results do not depend on the split (the same MFMAs in the same order per accumulator).
+  const int gw = blockIdx.x * 4 + wid;
+  const int q = nunit / nwave, r = nunit - q * nwave;
+  const int nf = 2 * r > nwave ? 2 * r - nwave : 0;
+  const int nfull = q + (gw < nf ? 1 : 0);
+  const int hk = gw - nf;                                   // index among the half-units
+  const bool has_half = hk >= 0 && hk < 2 * (r - nf);
+  const int half_unit = q * nwave + nf + (hk >> 1), half_h = hk & 1;
+  auto item_unit = [&](int i) { return i < nfull ? gw + i * nwave : half_unit; };   // i-th work item of this wave
+  const int nitem = nfull + (has_half ? 1 : 0);
+
   float d[16];
   f32x2w A0[8], A1[8];
   int voff = 0;
-  if (unit < nunit) {
-    voff = patch_voff(unit);
+  if (nitem > 0) {
+    voff = patch_voff(item_unit(0));
     load_patch(d, voff, 0);
     load_A(A0, 0, 0);
   }
-  for (; unit < nunit; unit += nwave) {
-    const int nvoff = patch_voff(unit + nwave < nunit ? unit + nwave : unit);
+  // HSEL: 2 = whole unit, 0 / 1 = the half-unit of output channels [0,16) / [16,32)
+  auto body = [&](auto hsel_tag, int unit, int next_unit) {
+    constexpr int HSEL = decltype(hsel_tag)::value;
+    const int nvoff = patch_voff(next_unit);
     // where this unit's outputs (and the mask) live
     const int t0 = unit * 16 + tl;
     const bool valid = t0 < ntile;
@@ -230,11 +249,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
             // position (1,1) enters all four outputs of the tile with weight +1: the bias rides in its accumulator
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             const f32x4 b0 = {bv[0][0], bv[0][1], bv[0][2], bv[0][3]}, b1 = {bv[1][0], bv[1][1], bv[1][2], bv[1][3]};
-            acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[0], V[pos], pos == 5 ? b0 : z, 0, 0, 0);
-            acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[1], V[pos], pos == 5 ? b1 : z, 0, 0, 0);
+            if constexpr (HSEL != 1) acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[0], V[pos], pos == 5 ? b0 : z, 0, 0, 0);
+            if constexpr (HSEL != 0) acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[1], V[pos], pos == 5 ? b1 : z, 0, 0, 0);
           } else {
-            acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[0], V[pos], acc[pos][0], 0, 0, 0);
-            acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[1], V[pos], acc[pos][1], 0, 0, 0);
+            if constexpr (HSEL != 1) acc[pos][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[0], V[pos], acc[pos][0], 0, 0, 0);
+            if constexpr (HSEL != 0) acc[pos][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ap[1], V[pos], acc[pos][1], 0, 0, 0);
           }
         }
       };
@@ -243,11 +262,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
       load_A(A0, (c + 1) & 7, 0);            // the next k-step's (or the next unit's first) lower half
       if constexpr (MASK) {
         if (c == 7) {                        // the first half of the mask flies under the unit's last sixteen MFMAs
+          constexpr int h0 = HSEL == 1 ? 1 : 0;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-              mk[0][r][i] = __builtin_amdgcn_raw_buffer_load_b64(mrs, mbase + i * (HOUT * 4), r * (HOUT * HOUT * 4), 0);
+              mk[h0][r][i] = __builtin_amdgcn_raw_buffer_load_b64(mrs, mbase + i * (HOUT * 4),
+                                                                  (16 * h0 + r) * (HOUT * HOUT * 4), 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -258,9 +279,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
     {
       if constexpr (ABL & 2) {               // every accumulator stays live although only four are stored
 #pragma unroll
-        for (int pos = 0; pos < 16; ++pos) asm volatile("" ::"v"(acc[pos][0]), "v"(acc[pos][1]));
+        for (int pos = 0; pos < 16; ++pos) {
+          if constexpr (HSEL != 1) asm volatile("" ::"v"(acc[pos][0]));
+          if constexpr (HSEL != 0) asm volatile("" ::"v"(acc[pos][1]));
+        }
       }
-      if constexpr (MASK) {                  // ... the second half under the first half's transform arithmetic
+      if constexpr (MASK && HSEL == 2) {     // ... the second half under the first half's transform arithmetic
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -270,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
       }
       const int ycs4 = a.y_cs * 4, yrs4 = a.y_rs * 4;
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int h = (HSEL == 1 ? 1 : 0); h < (HSEL == 0 ? 1 : 2); ++h)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float s[2][4];
@@ -304,6 +328,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
     }
     voff = nvoff;
     mark();
+  };
+  for (int i = 0; i < nfull; ++i) body(std::integral_constant<int, 2>{}, item_unit(i), item_unit(i + 1 < nitem ? i + 1 : i));
+  if (has_half) {
+    if (half_h == 0) body(std::integral_constant<int, 0>{}, half_unit, half_unit);
+    else body(std::integral_constant<int, 1>{}, half_unit, half_unit);
   }
   if constexpr (ABL & 8) {
     __builtin_amdgcn_s_waitcnt(0);
