@@ -47,6 +47,7 @@ PROTOTYPES = {
     "drq_conv3x3_dgrad": (I, [P, P, P, P, I, I, L, L, L, L, P]),
     "drq_conv3x3_fwd_wino": (I, [P, P, P, P, I, I, I, L, L, L, L, P]),
     "drq_conv3x3_dgrad_wino": (I, [P, P, P, P, I, I, L, L, L, L, P]),
+    "drq_conv3x3_wgrad_wino": (I, [P, P, P, P, I, I, L, L, L, L, P, SZ, P]),
     "drq_conv3x3_wgrad": (I, [P, P, P, P, I, I, I, I, L, L, L, L, P, SZ, P]),
     "drq_conv3x3_wgrad_ws_bytes": (SZ, []),
     "drq_conv3x3_fwd_bf16": (I, [P, P, P, P, I, I, I, L, L, L, L, P]),

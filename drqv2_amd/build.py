@@ -10,13 +10,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdrqv2_hip.so")
 LIB_DEV = os.path.join(HERE, "libdrqv2_hip_dev.so")
-SOURCES = ["conv.hip", "conv_wino.hip", "conv1aug.hip", "conv_bf16.hip", "gemm.hip", "gemm2.hip", "skinny.hip", "elementwise.hip", "rng.hip", "step.hip"]
+SOURCES = ["conv.hip", "conv_wino.hip", "conv_wino_wgrad.hip", "conv1aug.hip", "conv_bf16.hip", "gemm.hip", "gemm2.hip", "skinny.hip", "elementwise.hip", "rng.hip", "step.hip"]
 # per-file additions.  conv_wino.hip: hipcc's SLP vectoriser packs the transform adds into v_pk_add_f32 plus the
 # v_mov shuffles that feed them -- more VALU issue slots beside the MFMAs, not fewer (136 moves per unit)
 # rng.hip: hipRAND's Box-Muller (logf, sincosf, the scaling multiply-adds) must round like the copy inside torch's
 # own normal_() kernel: -ffp-contract=on does (0 of 65,536 values differ; hipcc's default fast contraction: 15 %
 # differ in the last bit; contraction off: 0.7 %) -- tools/rng_flags_probe.py, and the engine's self test at run time
-FILE_FLAGS = {"conv_wino.hip": ["-fno-slp-vectorize"], "rng.hip": ["-ffp-contract=on"]}
+FILE_FLAGS = {"conv_wino.hip": ["-fno-slp-vectorize"], "conv_wino_wgrad.hip": ["-fno-slp-vectorize"], "rng.hip": ["-ffp-contract=on"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-fvisibility=hidden"]
 

@@ -1176,6 +1176,10 @@ int launch_wgrad(const WgradArgs& a0, float* dw, float* db, float* ws, size_t ws
 
 }  // namespace
 
+// conv_wino_wgrad.hip
+int drq_conv3x3_wgrad_partial_wino(const float* x, const float* dy, int nb, int hin, long dy_bs, long dy_cs, long dy_rs,
+                                   long dy_off, float* part, size_t part_bytes, int* nblocks, hipStream_t st);
+
 // ---- internal entry points of the step orchestration (step.hip): per-layer partial sums now, one reduction later
 int drq_conv3x3_wgrad_partial(const float* x, const float* dy, int nb, int cin, int hin, int stride, long dy_bs,
                               long dy_cs, long dy_rs, long dy_off, float* part, size_t part_bytes, int* nblocks,
@@ -1280,6 +1284,21 @@ DRQ_API int drq_conv3x3_wgrad(const float* x, const float* dy, float* dw, float*
     if (hin == 37) return launch_wgrad<32, 37, 1>(a, dw, db, ws, ws_bytes, st);
   }
   return DRQ_EARG;
+}
+
+// The same gradients of the 32->32 layers in Winograd F(2x2,3x3) form (conv_wino_wgrad.hip): partial records in the
+// same format, the same fixed-order reduction.
+DRQ_API int drq_conv3x3_wgrad_wino(const float* x, const float* dy, float* dw, float* db, int nb, int hin, long dy_bs,
+                                   long dy_cs, long dy_rs, long dy_off, float* ws, size_t ws_bytes, hipStream_t st) {
+  if (!x || !dy || !dw || !db || !ws || nb <= 0) return DRQ_EARG;
+  int nblocks = 0;
+  const int rc = drq_conv3x3_wgrad_partial_wino(x, dy, nb, hin, dy_bs, dy_cs, dy_rs, dy_off, ws, ws_bytes, &nblocks, st);
+  if (rc != 0) return rc;
+  constexpr int PART = 9 * 1024 + 64;
+  hipLaunchKernelGGL((conv3x3_wgrad_reduce_kernel<32, false>), dim3(PART / 64), dim3(1024), 0, st, (const float*)ws,
+                     nblocks, dw, db);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
 }
 
 DRQ_API size_t drq_conv3x3_wgrad_ws_bytes(void) { return (size_t)1024 * (9 * 1024 + 64) * sizeof(float); }

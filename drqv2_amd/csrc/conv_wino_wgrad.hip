@@ -1,0 +1,247 @@
+// Weight gradient of the encoder's 32->32 layers in Winograd F(2x2,3x3) form on the f32 matrix cores.
+//
+// Reference op: the autograd weight / bias gradient of nn.Conv2d(32,32,3,1) (drqv2.py:56-58).  With
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A   per 2x2 output tile (conv_wino.hip),
+// the gradient of the loss with respect to g is
+//   dg = G^T [ sum over samples and tiles of (A dY A^T) .* (B^T d B) ] G      per (cout, cin):
+// 16 positions x a 32x32 (cout x cin) matrix, reduced over all tiles -- 16 tile-GEMMs instead of the direct form's
+// 9 pixel-GEMMs over four times as many pixels: 2.25x fewer matrix FLOPs.
+//
+// Mapping: v_mfma_f32_16x16x4_f32 with K = 4 tiles: D[cout 16][cin 16] += dM[cout][tile] * V[tile][cin].  Lane l holds
+// channel l&15 (+16 for the second half) and tile 4s + (l>>4) of step s of a tile row -- in BOTH roles: it loads that
+// channel's 2x2 dY patch (A operand, after A dY A^T) and that channel's 4x4 input patch (B operand, after B^T d B)
+// straight from global memory (the patches of the four tiles of a step are 40 contiguous bytes of a row: L2 serves the
+// re-touched lines).  A wave owns whole tile rows and keeps all 16 positions x 2x2 channel-half quadrants x 4 registers =
+// 256 accumulators (one wave per SIMD: the unified register file holds them as AGPRs).  At the end every wave maps its
+// sums back to 3x3 taps (G^T . G), the four waves of a workgroup are added through LDS in wave order and the workgroup
+// writes ONE partial record in the format of conv3x3_wgrad3_kernel (conv.hip): the same fixed-order reduction kernel
+// finishes the job (deterministic, no float atomics).
+#include "common.h"
+
+namespace {
+
+struct WWArgs {
+  const float* x;     // layer input  [NB][32][HIN][HIN]
+  const float* dy;    // grad of the pre-activation, zero-padded by 2, addressed with strides; dy_off = element (0,0)
+  int dy_bs, dy_cs, dy_rs, dy_off;
+  float* part;        // [nblocks][9*1024 + 64]
+  unsigned x_bytes, dy_bytes;
+  int nb;
+};
+
+typedef unsigned u32x4q __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2q __attribute__((ext_vector_type(2)));
+
+template <int HIN>
+__global__ __launch_bounds__(256, 1) void conv3x3_wgrad_wino_kernel(WWArgs a) {
+#pragma clang fp contract(off)
+  constexpr int HOUT = HIN - 2;
+  constexpr int TH = (HOUT + 1) / 2;          // tiles per row / tile rows per sample
+  constexpr int NS = (TH + 3) / 4;            // steps (4 tiles each) per tile row
+  constexpr int PLANE = HIN * HIN * 4;        // bytes of one input channel
+  constexpr int PART = 9 * 1024 + 64;
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][PART]
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ch = lane & 15, tq = lane >> 4;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
+  constexpr int kDrop = (int)0x80000000u;     // beyond num_records: the load returns 0
+  const int dcs4 = a.dy_cs * 4, drs4 = a.dy_rs * 4;
+
+  // work: tile rows (sample, ty) dealt round-robin to the waves of the grid, NS steps each
+  const int nrow = a.nb * TH;
+  const int nw = (int)gridDim.x * 4, gw = (int)blockIdx.x * 4 + wid;
+  const int myrows = gw < nrow ? (nrow - 1 - gw) / nw + 1 : 0;
+  const int total = myrows * NS;
+
+  // per-lane byte offsets of item it = (k-th tile row of this wave, step s): the x patch and the dY patch
+  auto item_off = [&](int it, int& xo, int& dyo) {
+    const int k = it / NS, s = it - k * NS;
+    const int u = gw + k * nw;
+    const int b = u / TH, ty = u - b * TH;
+    const int tx = 4 * s + tq;
+    const int txc = tx < TH ? tx : TH - 1;
+    xo = (((b * 32 + ch) * HIN + 2 * ty) * HIN + 2 * txc) * 4;
+    dyo = tx < TH ? (a.dy_off + b * a.dy_bs + ch * a.dy_cs + 2 * ty * a.dy_rs + 2 * tx) * 4 : kDrop;
+  };
+  float dx[2][16], dyv[2][4];
+  auto load_item = [&](int xo, int dyo) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const u32x4q v = __builtin_amdgcn_raw_buffer_load_b128(xrs, xo, h * (16 * PLANE) + i * (HIN * 4), 0);
+        const unsigned e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];
+        dx[h][i * 4 + 0] = __uint_as_float(e0);
+        dx[h][i * 4 + 1] = __uint_as_float(e1);
+        dx[h][i * 4 + 2] = __uint_as_float(e2);
+        dx[h][i * 4 + 3] = __uint_as_float(e3);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const u32x2q v = __builtin_amdgcn_raw_buffer_load_b64(drs, dyo, h * 16 * dcs4 + i * drs4, 0);
+        const unsigned e0 = v[0], e1 = v[1];
+        dyv[h][i * 2 + 0] = __uint_as_float(e0);
+        dyv[h][i * 2 + 1] = __uint_as_float(e1);
+      }
+    }
+  };
+
+  f32x4 acc[16][2][2];                        // [position][cout half][cin half]
+#pragma unroll
+  for (int p = 0; p < 16; ++p)
+#pragma unroll
+    for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) acc[p][qa][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum[2] = {0.f, 0.f};                 // bias gradient: sum of this lane's dY values per channel half
+
+  if (total > 0) {
+    int xo, dyo;
+    item_off(0, xo, dyo);
+    load_item(xo, dyo);
+  }
+  for (int it = 0; it < total; ++it) {
+    int nxo, ndyo;
+    item_off(it + 1 < total ? it + 1 : it, nxo, ndyo);
+    float V[2][16], M[2][16];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      // V = B^T d B
+      float t[16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        t[0 * 4 + j] = dx[h][0 * 4 + j] - dx[h][2 * 4 + j];
+        t[1 * 4 + j] = dx[h][1 * 4 + j] + dx[h][2 * 4 + j];
+        t[2 * 4 + j] = dx[h][2 * 4 + j] - dx[h][1 * 4 + j];
+        t[3 * 4 + j] = dx[h][1 * 4 + j] - dx[h][3 * 4 + j];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        V[h][i * 4 + 0] = t[i * 4 + 0] - t[i * 4 + 2];
+        V[h][i * 4 + 1] = t[i * 4 + 1] + t[i * 4 + 2];
+        V[h][i * 4 + 2] = t[i * 4 + 2] - t[i * 4 + 1];
+        V[h][i * 4 + 3] = t[i * 4 + 1] - t[i * 4 + 3];
+      }
+      // dM = A dY A^T, A = [[1,0],[1,1],[1,-1],[0,-1]]
+      const float y00 = dyv[h][0], y01 = dyv[h][1], y10 = dyv[h][2], y11 = dyv[h][3];
+      bsum[h] += (y00 + y01) + (y10 + y11);
+      const float r[4][2] = {{y00, y01}, {y00 + y10, y01 + y11}, {y00 - y10, y01 - y11}, {-y10, -y11}};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        M[h][i * 4 + 0] = r[i][0];
+        M[h][i * 4 + 1] = r[i][0] + r[i][1];
+        M[h][i * 4 + 2] = r[i][0] - r[i][1];
+        M[h][i * 4 + 3] = -r[i][1];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    load_item(nxo, ndyo);                     // the next step's patches fly under this step's 64 MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+      for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+          acc[p][qa][qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(M[qa][p], V[qb][p], acc[p][qa][qb], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // ---- dg = G^T dU G per (cout, cin) -> this wave's image of the partial record in LDS
+  // D register r of lane l: cout = 16*qa + 4*(l>>4) + r, cin = 16*qb + (l&15)
+  // record element of (cout, cin, tap): tap*1024 + rr*64 + half*32 + cin with cout = (rr&3) + 8*(rr>>2) + 4*half
+  float* mine = red + wid * PART;
+#pragma unroll
+  for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float u[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) u[i][j] = acc[i * 4 + j][qa][qb][r];
+        float tm[3][4];                        // G^T u
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float hs = 0.5f * (u[1][j] + u[2][j]), hd = 0.5f * (u[1][j] - u[2][j]);
+          tm[0][j] = u[0][j] + hs;
+          tm[1][j] = hd;
+          tm[2][j] = hs + u[3][j];
+        }
+        const int co = 16 * qa + 4 * tq + r, ci = 16 * qb + ch;
+        const int half = (co >> 2) & 1, rr = (co & 3) + 4 * (co >> 3);
+        float* dst = mine + rr * 64 + half * 32 + ci;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const float hs = 0.5f * (tm[ky][1] + tm[ky][2]), hd = 0.5f * (tm[ky][1] - tm[ky][2]);
+          dst[(ky * 3 + 0) * 1024] = tm[ky][0] + hs;
+          dst[(ky * 3 + 1) * 1024] = hd;
+          dst[(ky * 3 + 2) * 1024] = hs + tm[ky][3];
+        }
+      }
+  // bias: lanes with the same channel (4 tile quarters) are added by the record reduction's two slots and here
+  {
+    float b0 = bsum[0], b1 = bsum[1];
+    b0 += __shfl_xor(b0, 16); b0 += __shfl_xor(b0, 32);
+    b1 += __shfl_xor(b1, 16); b1 += __shfl_xor(b1, 32);
+    if (lane < 16) {
+      mine[9 * 1024 + ch] = b0;
+      mine[9 * 1024 + 16 + ch] = b1;
+      mine[9 * 1024 + 32 + ch] = 0.f;
+      mine[9 * 1024 + 48 + ch] = 0.f;
+    }
+  }
+  __syncthreads();
+  float4* out = reinterpret_cast<float4*>(a.part + (long)blockIdx.x * PART);
+  const float4* r4 = reinterpret_cast<const float4*>(red);
+  for (int i = threadIdx.x; i < PART / 4; i += 256) {
+    const float4 p = r4[i], q = r4[PART / 4 + i], v = r4[2 * (PART / 4) + i], w = r4[3 * (PART / 4) + i];
+    out[i] = make_float4((p.x + q.x) + (v.x + w.x), (p.y + q.y) + (v.y + w.y), (p.z + q.z) + (v.z + w.z),
+                         (p.w + q.w) + (v.w + w.w));
+  }
+}
+
+template <int HIN>
+int launch_ww(const WWArgs& a, int* nblocks, hipStream_t st) {
+  constexpr int PART = 9 * 1024 + 64;
+  constexpr int lds = 4 * PART * 4;
+  static bool attr_dev[kMaxDevices] = {};
+  bool& attr = attr_dev[drq_device()];
+  if (!attr) {
+    const hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wgrad_wino_kernel<HIN>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  constexpr int TH = (HIN - 1) / 2;
+  long blocks = drq_num_cus();
+  const long rows = (long)a.nb * TH;
+  if (blocks * 4 > rows) blocks = (rows + 3) / 4;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL((conv3x3_wgrad_wino_kernel<HIN>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+  DRQ_LAUNCH_CHECK();
+  *nblocks = (int)blocks;
+  return DRQ_OK;
+}
+
+}  // namespace
+
+// internal (step.hip, conv.hip's public entry): partial records of the 32->32 weight gradient in Winograd form, same
+// record format and reduction as drq_conv3x3_wgrad_partial
+int drq_conv3x3_wgrad_partial_wino(const float* x, const float* dy, int nb, int hin, long dy_bs, long dy_cs, long dy_rs,
+                                   long dy_off, float* part, size_t part_bytes, int* nblocks, hipStream_t st) {
+  if (!x || !dy || !part || !nblocks || nb <= 0) return DRQ_EARG;
+  const size_t xb = (size_t)nb * 32 * hin * hin * 4;
+  const size_t dyb = (size_t)nb * dy_bs * 4;
+  if (xb >= (1ull << 31) || dyb >= (1ull << 31) || dy_off < 0 || dy_bs <= 0) return DRQ_EARG;
+  if ((size_t)drq_num_cus() * (9 * 1024 + 64) * sizeof(float) > part_bytes) return DRQ_EWS;
+  if (((size_t)part & 15) != 0) return DRQ_EARG;
+  WWArgs a{x, dy, (int)dy_bs, (int)dy_cs, (int)dy_rs, (int)dy_off, part, (unsigned)xb, (unsigned)dyb, nb};
+  if (hin == 41) return launch_ww<41>(a, nblocks, st);
+  if (hin == 39) return launch_ww<39>(a, nblocks, st);
+  if (hin == 37) return launch_ww<37>(a, nblocks, st);
+  return DRQ_EARG;
+}

@@ -123,7 +123,7 @@ def conv3x3_dgrad(dy_pad, w, mask, bf16=False, wino=False):
     return dx
 
 
-def conv3x3_wgrad(x, dy, stride, bf16=False):
+def conv3x3_wgrad(x, dy, stride, bf16=False, wino=False):
     """x [nb,cin,hin,hin], dy [nb,32,hout,hout] (any strides with unit x-stride) -> dw, db."""
     lib = _lib.load()
     _need(x, name="x")
@@ -134,6 +134,10 @@ def conv3x3_wgrad(x, dy, stride, bf16=False):
     db = torch.empty((32,), device=x.device, dtype=torch.float32)
     nbytes = lib.drq_conv3x3_wgrad_ws_bytes()
     ws = torch.empty((nbytes // 4,), device=x.device, dtype=torch.float32)
+    if wino:        # dy must be the interior view of a buffer zero-padded by 2 (the kernel reads the padding as zeros)
+        check(lib.drq_conv3x3_wgrad_wino(ptr(x), dy.data_ptr(), ptr(dw), ptr(db), nb, hin, dy.stride(0), dy.stride(1),
+                                         dy.stride(2), 0, ptr(ws), nbytes, _stream()), "drq_conv3x3_wgrad_wino")
+        return dw, db
     if bf16:
         check(lib.drq_conv3x3_wgrad_bf16(ptr(x), dy.data_ptr(), ptr(dw), ptr(db), nb, hin, dy.stride(0), dy.stride(1),
                                          dy.stride(2), 0, ptr(ws), nbytes, _stream()), "drq_conv3x3_wgrad_bf16")

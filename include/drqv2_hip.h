@@ -71,6 +71,9 @@ int drq_conv3x3_fwd_wino(const float* x, const float* w, const float* bias, floa
                          long y_bs, long y_cs, long y_rs, long y_off, drq_stream_t stream);
 int drq_conv3x3_dgrad_wino(const float* dy_pad, const float* w, const float* mask, float* dx, int nb, int hout,
                            long dx_bs, long dx_cs, long dx_rs, long dx_off, drq_stream_t stream);
+/* ... and their weight / bias gradient in the same form (same contract as drq_conv3x3_wgrad for cin = 32, stride 1). */
+int drq_conv3x3_wgrad_wino(const float* x, const float* dy, float* dw, float* db, int nb, int hin, long dy_bs,
+                           long dy_cs, long dy_rs, long dy_off, float* ws, size_t ws_bytes, drq_stream_t stream);
 /* dw [32][cin][3][3], db [32]; dy addressed as dy[dy_off + b*dy_bs + co*dy_cs + oy*dy_rs + ox]. */
 int drq_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, int nb, int cin, int hin,
                       int stride, long dy_bs, long dy_cs, long dy_rs, long dy_off, float* ws, size_t ws_bytes,

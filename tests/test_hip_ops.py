@@ -146,6 +146,25 @@ def test_conv_dgrad_winograd(ops, hout, nb):
     assert bool((border == 7.0).all())
 
 
+@pytest.mark.parametrize("hin,nb", [(41, 5), (39, 2), (37, 7), (41, 1), (37, 64), (39, 256)])
+def test_conv_wgrad_winograd(ops, hin, nb):
+    """The update's weight / bias gradient of the 32->32 layers (Winograd form, drq_conv3x3_wgrad_wino): same bound
+    against fp64 as the direct kernel; dY is the interior view of the zero-padded buffer, as the update stores it
+    (the kernel relies on that padding for the half-empty last tile row / column and for the ragged last step)."""
+    hout = hin - 2
+    x = rnd(nb, 32, hin, hin, seed=7).clamp_min(0)
+    dy = rnd(nb, 32, hout, hout, seed=8)
+    dy_pad = F.pad(dy, (2, 2, 2, 2)).contiguous().cuda()
+    dw, db = ops.conv3x3_wgrad(x.cuda(), dy_pad[:, :, 2:-2, 2:-2], 1, wino=True)
+    xd = x.double()
+    wd = torch.zeros(32, 32, 3, 3, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(xd, wd) * dy.double()).sum().backward()
+    assert nerr(dw, wd.grad) <= 3e-6
+    assert nerr(db, dy.double().sum((0, 2, 3))) <= 3e-6
+    dw_d, db_d = ops.conv3x3_wgrad(x.cuda(), dy_pad[:, :, 2:-2, 2:-2], 1)
+    assert nerr(dw, dw_d.double().cpu()) <= 3e-6 and nerr(db, db_d.double().cpu()) <= 3e-6
+
+
 @pytest.mark.parametrize("cin,hin,stride,nb", [(9, 84, 2, 3), (32, 41, 1, 5), (32, 39, 1, 2), (32, 37, 1, 7)])
 def test_conv_wgrad(ops, cin, hin, stride, nb):
     hout = (hin - 3) // stride + 1

@@ -48,3 +48,17 @@ for hout in (35, 37, 39):
     gf = B * hin ** 2 * 18432 / 1e9
     print(f"dgrad hout {hout} nb {B}: direct {td:7.1f} us ({gf/td*1e3:6.1f} TF)  wino {tw:7.1f} us ({gf/tw*1e3:6.1f} TF-equiv)  "
           f"x{td/tw:.2f}  diff {err:.1e}", flush=True)
+for hin in (37, 39, 41):
+    hout = hin - 2
+    x = rn(B, 32, hin, hin).clamp_min(0)
+    dyp = torch.zeros(B, 32, hout + 4, hout + 4, device="cuda")
+    dyp[:, :, 2:-2, 2:-2] = rn(B, 32, hout, hout)
+    dyv = dyp[:, :, 2:-2, 2:-2]
+    wd, bd = ops.conv3x3_wgrad(x, dyv, 1)
+    ww, bw = ops.conv3x3_wgrad(x, dyv, 1, wino=True)
+    err = float((wd - ww).norm() / wd.norm())
+    td = timeit(lambda: ops.conv3x3_wgrad(x, dyv, 1))
+    tw = timeit(lambda: ops.conv3x3_wgrad(x, dyv, 1, wino=True))
+    gf = B * hout ** 2 * 18432 / 1e9
+    print(f"wgrad hin {hin} nb {B}: direct {td:7.1f} us ({gf/td*1e3:6.1f} TF)  wino {tw:7.1f} us ({gf/tw*1e3:6.1f} TF-equiv)  "
+          f"x{td/tw:.2f}  diff {err:.1e}  (both incl. their record reduction)", flush=True)
