@@ -11,7 +11,7 @@
 // channel l&15 (+16 for the second half) and tile 4s + (l>>4) of step s of a tile row -- in BOTH roles: it loads that
 // channel's 2x2 dY patch (A operand, after A dY A^T) and that channel's 4x4 input patch (B operand, after B^T d B)
 // straight from global memory (the patches of the four tiles of a step are 40 contiguous bytes of a row: L2 serves the
-// re-touched lines).  A wave owns whole tile rows and keeps all 16 positions x 2x2 channel-half quadrants x 4 registers =
+// re-touched lines).  A wave takes steps of four consecutive tiles round-robin and keeps all 16 positions x 2x2 channel-half quadrants x 4 registers =
 // 256 accumulators (one wave per SIMD: the unified register file holds them as AGPRs).  At the end every wave maps its
 // sums back to 3x3 taps (G^T . G), the four waves of a workgroup are added through LDS in wave order and the workgroup
 // writes ONE partial record in the format of conv3x3_wgrad3_kernel (conv.hip): the same fixed-order reduction kernel
@@ -32,12 +32,16 @@ struct WWArgs {
 typedef unsigned u32x4q __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2q __attribute__((ext_vector_type(2)));
 
-template <int HIN>
+#ifdef DRQ_DEV
+int g_ww_variant = 0;   // drq_dev_wgrad_wino_variant: timing ablations (tools/wino_ab.py)
+#endif
+
+// ABL (development build only): 1 = no patch loads, 2 = no transforms (the raw patches are multiplied); wrong results
+template <int HIN, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_wino_kernel(WWArgs a) {
 #pragma clang fp contract(off)
   constexpr int HOUT = HIN - 2;
   constexpr int TH = (HOUT + 1) / 2;          // tiles per row / tile rows per sample
-  constexpr int NS = (TH + 3) / 4;            // steps (4 tiles each) per tile row
   constexpr int PLANE = HIN * HIN * 4;        // bytes of one input channel
   constexpr int PART = 9 * 1024 + 64;
   extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][PART]
@@ -48,41 +52,53 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_wino_kernel(WWArgs a) {
   constexpr int kDrop = (int)0x80000000u;     // beyond num_records: the load returns 0
   const int dcs4 = a.dy_cs * 4, drs4 = a.dy_rs * 4;
 
-  // work: tile rows (sample, ty) dealt round-robin to the waves of the grid, NS steps each
-  const int nrow = a.nb * TH;
+  // work: steps of 4 consecutive tiles of the flattened (sample, tile row, tile column) index, dealt round-robin to
+  // the waves of the grid (a step may straddle two tile rows: every lane places its own tile)
+  constexpr int TT = TH * TH;
+  const int ntile = a.nb * TT;
+  const int nstep = (ntile + 3) >> 2;
   const int nw = (int)gridDim.x * 4, gw = (int)blockIdx.x * 4 + wid;
-  const int myrows = gw < nrow ? (nrow - 1 - gw) / nw + 1 : 0;
-  const int total = myrows * NS;
+  const int total = gw < nstep ? (nstep - 1 - gw) / nw + 1 : 0;
 
-  // per-lane byte offsets of item it = (k-th tile row of this wave, step s): the x patch and the dY patch
+  // per-lane byte offsets of this wave's it-th step: the x patch and the dY patch
   auto item_off = [&](int it, int& xo, int& dyo) {
-    const int k = it / NS, s = it - k * NS;
-    const int u = gw + k * nw;
-    const int b = u / TH, ty = u - b * TH;
-    const int tx = 4 * s + tq;
-    const int txc = tx < TH ? tx : TH - 1;
-    xo = (((b * 32 + ch) * HIN + 2 * ty) * HIN + 2 * txc) * 4;
-    dyo = tx < TH ? (a.dy_off + b * a.dy_bs + ch * a.dy_cs + 2 * ty * a.dy_rs + 2 * tx) * 4 : kDrop;
+    const int t = 4 * (gw + it * nw) + tq;
+    const int tc = t < ntile ? t : ntile - 1;
+    const int b = tc / TT, rem = tc - b * TT;
+    const int ty = rem / TH, tx = rem - ty * TH;
+    xo = (((b * 32 + ch) * HIN + 2 * ty) * HIN + 2 * tx) * 4;
+    dyo = t < ntile ? (a.dy_off + b * a.dy_bs + ch * a.dy_cs + 2 * ty * a.dy_rs + 2 * tx) * 4 : kDrop;
   };
-  float dx[2][16], dyv[2][4];
-  auto load_item = [&](int xo, int dyo) {
+  // two register sets of patches: the loads of step it+2 are issued while step it multiplies (one wave per SIMD has
+  // nobody else to hide an HBM miss behind: one step = 64 MFMAs = 2048 matrix cycles is not always enough)
+  auto load_item = [&](float (&Pdx)[2][16], float (&Pdy)[2][4], int xo, int dyo) {
+    if constexpr (ABL & 1) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Pdx[h][e] = 1.0f + (float)(xo + e);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Pdy[h][e] = 0.5f + (float)(dyo + e);
+      }
+      return;
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const u32x4q v = __builtin_amdgcn_raw_buffer_load_b128(xrs, xo, h * (16 * PLANE) + i * (HIN * 4), 0);
         const unsigned e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];
-        dx[h][i * 4 + 0] = __uint_as_float(e0);
-        dx[h][i * 4 + 1] = __uint_as_float(e1);
-        dx[h][i * 4 + 2] = __uint_as_float(e2);
-        dx[h][i * 4 + 3] = __uint_as_float(e3);
+        Pdx[h][i * 4 + 0] = __uint_as_float(e0);
+        Pdx[h][i * 4 + 1] = __uint_as_float(e1);
+        Pdx[h][i * 4 + 2] = __uint_as_float(e2);
+        Pdx[h][i * 4 + 3] = __uint_as_float(e3);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const u32x2q v = __builtin_amdgcn_raw_buffer_load_b64(drs, dyo, h * 16 * dcs4 + i * drs4, 0);
         const unsigned e0 = v[0], e1 = v[1];
-        dyv[h][i * 2 + 0] = __uint_as_float(e0);
-        dyv[h][i * 2 + 1] = __uint_as_float(e1);
+        Pdy[h][i * 2 + 0] = __uint_as_float(e0);
+        Pdy[h][i * 2 + 1] = __uint_as_float(e1);
       }
     }
   };
@@ -96,14 +112,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_wino_kernel(WWArgs a) {
       for (int qb = 0; qb < 2; ++qb) acc[p][qa][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bsum[2] = {0.f, 0.f};                 // bias gradient: sum of this lane's dY values per channel half
 
-  if (total > 0) {
-    int xo, dyo;
-    item_off(0, xo, dyo);
-    load_item(xo, dyo);
-  }
-  for (int it = 0; it < total; ++it) {
+  // one step: transforms of the patches in P, then P is refilled with item `nit`, then the 64 MFMAs
+  auto step = [&](float (&Pdx)[2][16], float (&Pdy)[2][4], int nit) {
     int nxo, ndyo;
-    item_off(it + 1 < total ? it + 1 : it, nxo, ndyo);
+    item_off(nit < total ? nit : total - 1, nxo, ndyo);
     float V[2][16], M[2][16];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -111,24 +123,33 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_wino_kernel(WWArgs a) {
       float t[16];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        t[0 * 4 + j] = dx[h][0 * 4 + j] - dx[h][2 * 4 + j];
-        t[1 * 4 + j] = dx[h][1 * 4 + j] + dx[h][2 * 4 + j];
-        t[2 * 4 + j] = dx[h][2 * 4 + j] - dx[h][1 * 4 + j];
-        t[3 * 4 + j] = dx[h][1 * 4 + j] - dx[h][3 * 4 + j];
+        t[0 * 4 + j] = Pdx[h][0 * 4 + j] - Pdx[h][2 * 4 + j];
+        t[1 * 4 + j] = Pdx[h][1 * 4 + j] + Pdx[h][2 * 4 + j];
+        t[2 * 4 + j] = Pdx[h][2 * 4 + j] - Pdx[h][1 * 4 + j];
+        t[3 * 4 + j] = Pdx[h][1 * 4 + j] - Pdx[h][3 * 4 + j];
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
+        if constexpr (ABL & 2) {
+          V[h][i * 4 + 0] = Pdx[h][i * 4 + 0]; V[h][i * 4 + 1] = Pdx[h][i * 4 + 1];
+          V[h][i * 4 + 2] = Pdx[h][i * 4 + 2]; V[h][i * 4 + 3] = Pdx[h][i * 4 + 3];
+          continue;
+        }
         V[h][i * 4 + 0] = t[i * 4 + 0] - t[i * 4 + 2];
         V[h][i * 4 + 1] = t[i * 4 + 1] + t[i * 4 + 2];
         V[h][i * 4 + 2] = t[i * 4 + 2] - t[i * 4 + 1];
         V[h][i * 4 + 3] = t[i * 4 + 1] - t[i * 4 + 3];
       }
       // dM = A dY A^T, A = [[1,0],[1,1],[1,-1],[0,-1]]
-      const float y00 = dyv[h][0], y01 = dyv[h][1], y10 = dyv[h][2], y11 = dyv[h][3];
+      const float y00 = Pdy[h][0], y01 = Pdy[h][1], y10 = Pdy[h][2], y11 = Pdy[h][3];
       bsum[h] += (y00 + y01) + (y10 + y11);
       const float r[4][2] = {{y00, y01}, {y00 + y10, y01 + y11}, {y00 - y10, y01 - y11}, {-y10, -y11}};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
+        if constexpr (ABL & 2) {
+          M[h][i * 4 + 0] = Pdy[h][0]; M[h][i * 4 + 1] = Pdy[h][1]; M[h][i * 4 + 2] = Pdy[h][2]; M[h][i * 4 + 3] = Pdy[h][3];
+          continue;
+        }
         M[h][i * 4 + 0] = r[i][0];
         M[h][i * 4 + 1] = r[i][0] + r[i][1];
         M[h][i * 4 + 2] = r[i][0] - r[i][1];
@@ -136,7 +157,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_wino_kernel(WWArgs a) {
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    load_item(nxo, ndyo);                     // the next step's patches fly under this step's 64 MFMAs
+    load_item(Pdx, Pdy, nxo, ndyo);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int p = 0; p < 16; ++p)
@@ -146,7 +167,22 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_wino_kernel(WWArgs a) {
         for (int qb = 0; qb < 2; ++qb)
           acc[p][qa][qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(M[qa][p], V[qb][p], acc[p][qa][qb], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
+  };
+
+  float dx0[2][16], dy0[2][4], dx1[2][16], dy1[2][4];
+  if (total > 0) {
+    int xo, dyo;
+    item_off(0, xo, dyo);
+    load_item(dx0, dy0, xo, dyo);
+    item_off(total > 1 ? 1 : 0, xo, dyo);
+    load_item(dx1, dy1, xo, dyo);
   }
+  int it = 0;
+  for (; it + 1 < total; it += 2) {           // set 0 holds the even items, set 1 the odd ones
+    step(dx0, dy0, it + 2);
+    step(dx1, dy1, it + 3);
+  }
+  if (it < total) step(dx0, dy0, it + 2);
 
   // ---- dg = G^T dU G per (cout, cin) -> this wave's image of the partial record in LDS
   // D register r of lane l: cout = 16*qa + 4*(l>>4) + r, cin = 16*qb + (l&15)
@@ -218,9 +254,22 @@ int launch_ww(const WWArgs& a, int* nblocks, hipStream_t st) {
   }
   constexpr int TH = (HIN - 1) / 2;
   long blocks = drq_num_cus();
-  const long rows = (long)a.nb * TH;
-  if (blocks * 4 > rows) blocks = (rows + 3) / 4;
+  const long steps = ((long)a.nb * TH * TH + 3) / 4;
+  if (blocks * 4 > steps) blocks = (steps + 3) / 4;
   if (blocks < 1) blocks = 1;
+#ifdef DRQ_DEV
+  if (g_ww_variant) {
+    const void* fn = g_ww_variant == 1 ? (const void*)conv3x3_wgrad_wino_kernel<HIN, 1>
+                   : g_ww_variant == 2 ? (const void*)conv3x3_wgrad_wino_kernel<HIN, 2> : (const void*)conv3x3_wgrad_wino_kernel<HIN, 3>;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (g_ww_variant == 1) hipLaunchKernelGGL((conv3x3_wgrad_wino_kernel<HIN, 1>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+    else if (g_ww_variant == 2) hipLaunchKernelGGL((conv3x3_wgrad_wino_kernel<HIN, 2>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((conv3x3_wgrad_wino_kernel<HIN, 3>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+    DRQ_LAUNCH_CHECK();
+    *nblocks = (int)blocks;
+    return DRQ_OK;
+  }
+#endif
   hipLaunchKernelGGL((conv3x3_wgrad_wino_kernel<HIN>), dim3((unsigned)blocks), dim3(256), lds, st, a);
   DRQ_LAUNCH_CHECK();
   *nblocks = (int)blocks;
@@ -228,6 +277,10 @@ int launch_ww(const WWArgs& a, int* nblocks, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef DRQ_DEV
+extern "C" DRQ_API void drq_dev_wgrad_wino_variant(int v) { g_ww_variant = v; }
+#endif
 
 // internal (step.hip, conv.hip's public entry): partial records of the 32->32 weight gradient in Winograd form, same
 // record format and reduction as drq_conv3x3_wgrad_partial

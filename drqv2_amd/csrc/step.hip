@@ -74,6 +74,9 @@ int drq_conv3x3_wgrad_partial_bf16(const float* x, const float* dy, int nb, int 
 int drq_conv3x3_wgrad_partial(const float* x, const float* dy, int nb, int cin, int hin, int stride, long dy_bs,
                               long dy_cs, long dy_rs, long dy_off, float* part, size_t part_bytes, int* nblocks,
                               hipStream_t st);
+// conv_wino_wgrad.hip (internal): the 32->32 layers' records in Winograd form (same format, same reduction)
+int drq_conv3x3_wgrad_partial_wino(const float* x, const float* dy, int nb, int hin, long dy_bs, long dy_cs, long dy_rs,
+                                   long dy_off, float* part, size_t part_bytes, int* nblocks, hipStream_t st);
 int drq_conv3x3_wgrad_reduce_multi(int n, const float* const* part, const int* nblocks, const int* cin,
                                    float* const* dw, float* const* db, hipStream_t st);
 
@@ -548,6 +551,9 @@ int phase_conv_backward(const Ctx& c) {
     float* part = cws + (size_t)l * (quarter / sizeof(float));
     if (c.bf16() && l > 0)
       CK(drq_conv3x3_wgrad_partial_bf16(c.ws(actid[l]), dy, B, hin, 32L * hp * hp, (long)hp * hp, hp, 2L * hp + 2, part,
+                                        quarter, &nblk[l], st));
+    else if (l > 0)   // Winograd form (conv_wino_wgrad.hip); it reads dY's zero padding
+      CK(drq_conv3x3_wgrad_partial_wino(c.ws(actid[l]), dy, B, hin, 32L * hp * hp, (long)hp * hp, hp, 2L * hp + 2, part,
                                         quarter, &nblk[l], st));
     else
     CK(drq_conv3x3_wgrad_partial(c.ws(actid[l]), dy, B, l == 0 ? C : 32, hin, l == 0 ? 2 : 1, 32L * hp * hp,

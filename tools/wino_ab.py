@@ -45,3 +45,16 @@ for rep in range(2):
         tf = timeit(lambda: ops.conv3x3_fwd(x, w, b, 1, wino=True))
         td = timeit(lambda: ops.conv3x3_dgrad(dyp, w, mask, wino=True))
         print(f"stagger {sg:2d} x 1024 clocks: fwd hin 41 {tf:7.1f} us   dgrad hout 37 {td:7.1f} us", flush=True)
+
+# ---- the weight-gradient kernel (conv3x3_wgrad_wino_kernel), conv2's shape
+lib.drq_dev_wgrad_wino_variant.argtypes = [ctypes.c_int]
+xw = rn(B, 32, 41, 41).clamp_min(0)
+dyw = torch.zeros(B, 32, 43, 43, device="cuda")
+dyw[:, :, 2:-2, 2:-2] = rn(B, 32, 39, 39)
+dyv = dyw[:, :, 2:-2, 2:-2]
+wn = {0: "full", 1: "no patch loads", 2: "no transforms", 3: "neither (MFMAs + epilogue)"}
+for rep in range(2):
+    for v in (0, 1, 2, 3):
+        lib.drq_dev_wgrad_wino_variant(v)
+        print(f"wgrad variant {v} ({wn[v]:28s}): {timeit(lambda: ops.conv3x3_wgrad(xw, dyv, 1, wino=True)):7.1f} us (incl. the ~8 us record reduction)", flush=True)
+lib.drq_dev_wgrad_wino_variant(0)
