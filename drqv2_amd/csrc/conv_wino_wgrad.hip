@@ -140,10 +140,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_wino_kernel(WWArgs a) {
         V[h][i * 4 + 2] = t[i * 4 + 2] - t[i * 4 + 1];
         V[h][i * 4 + 3] = t[i * 4 + 1] - t[i * 4 + 3];
       }
-      // dM = A dY A^T, A = [[1,0],[1,1],[1,-1],[0,-1]]
+      // dM' = A' dY A'^T with A' = [[1,0],[1,1],[1,-1],[0,1]]: the last row of A = [0,-1] with its sign flipped (no
+      // negations here); dM = S dM' S with S = diag(1,1,1,-1), and S moves into the final transform: dg = (SG)^T dU' (SG)
       const float y00 = Pdy[h][0], y01 = Pdy[h][1], y10 = Pdy[h][2], y11 = Pdy[h][3];
       bsum[h] += (y00 + y01) + (y10 + y11);
-      const float r[4][2] = {{y00, y01}, {y00 + y10, y01 + y11}, {y00 - y10, y01 - y11}, {-y10, -y11}};
+      const float r[4][2] = {{y00, y01}, {y00 + y10, y01 + y11}, {y00 - y10, y01 - y11}, {y10, y11}};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if constexpr (ABL & 2) {
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_wino_kernel(WWArgs a) {
         M[h][i * 4 + 0] = r[i][0];
         M[h][i * 4 + 1] = r[i][0] + r[i][1];
         M[h][i * 4 + 2] = r[i][0] - r[i][1];
-        M[h][i * 4 + 3] = -r[i][1];
+        M[h][i * 4 + 3] = r[i][1];
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -199,13 +200,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_wino_kernel(WWArgs a) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) u[i][j] = acc[i * 4 + j][qa][qb][r];
-        float tm[3][4];                        // G^T u
+        float tm[3][4];                        // (SG)^T u: G with the sign of its last row flipped (see dM' above)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float hs = 0.5f * (u[1][j] + u[2][j]), hd = 0.5f * (u[1][j] - u[2][j]);
           tm[0][j] = u[0][j] + hs;
           tm[1][j] = hd;
-          tm[2][j] = hs + u[3][j];
+          tm[2][j] = hs - u[3][j];
         }
         const int co = 16 * qa + 4 * tq + r, ci = 16 * qb + ch;
         const int half = (co >> 2) & 1, rr = (co & 3) + 4 * (co >> 3);
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_wino_kernel(WWArgs a) {
           const float hs = 0.5f * (tm[ky][1] + tm[ky][2]), hd = 0.5f * (tm[ky][1] - tm[ky][2]);
           dst[(ky * 3 + 0) * 1024] = tm[ky][0] + hs;
           dst[(ky * 3 + 1) * 1024] = hd;
-          dst[(ky * 3 + 2) * 1024] = hs + tm[ky][3];
+          dst[(ky * 3 + 2) * 1024] = hs - tm[ky][3];
         }
       }
   // bias: lanes with the same channel (4 tile quarters) are added by the record reduction's two slots and here
