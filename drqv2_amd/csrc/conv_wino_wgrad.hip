@@ -103,6 +103,35 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_wino_kernel(WWArgs a) {
     }
   };
 
+  // the k-th of the twelve load instructions of an item: 0..7 = x rows (h = k>>2, i = k&3), 8..11 = dY rows
+  auto load_one = [&](float (&Pdx)[2][16], float (&Pdy)[2][4], int xo, int dyo, int k) {
+    if constexpr (ABL & 1) {
+      if (k < 8) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Pdx[k >> 2][(k & 3) * 4 + e] = 1.0f + (float)(xo + e + k);
+      } else {
+        Pdy[(k - 8) >> 1][((k - 8) & 1) * 2 + 0] = 0.5f + (float)(dyo + k);
+        Pdy[(k - 8) >> 1][((k - 8) & 1) * 2 + 1] = 0.25f + (float)(dyo + k);
+      }
+      return;
+    }
+    if (k < 8) {
+      const int h = k >> 2, i = k & 3;
+      const u32x4q v = __builtin_amdgcn_raw_buffer_load_b128(xrs, xo, h * (16 * PLANE) + i * (HIN * 4), 0);
+      const unsigned e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];
+      Pdx[h][i * 4 + 0] = __uint_as_float(e0);
+      Pdx[h][i * 4 + 1] = __uint_as_float(e1);
+      Pdx[h][i * 4 + 2] = __uint_as_float(e2);
+      Pdx[h][i * 4 + 3] = __uint_as_float(e3);
+    } else {
+      const int h = (k - 8) >> 1, i = (k - 8) & 1;
+      const u32x2q v = __builtin_amdgcn_raw_buffer_load_b64(drs, dyo, h * 16 * dcs4 + i * drs4, 0);
+      const unsigned e0 = v[0], e1 = v[1];
+      Pdy[h][i * 2 + 0] = __uint_as_float(e0);
+      Pdy[h][i * 2 + 1] = __uint_as_float(e1);
+    }
+  };
+
   f32x4 acc[16][2][2];                        // [position][cout half][cin half]
 #pragma unroll
   for (int p = 0; p < 16; ++p)
@@ -157,33 +186,33 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_wino_kernel(WWArgs a) {
         M[h][i * 4 + 3] = r[i][1];
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    load_item(Pdx, Pdy, nxo, ndyo);
+    // The refill's twelve loads are spread over the step's 64 MFMAs, three ahead of every sixteen: a wave issues in
+    // order, so a burst of loads that backs up in the texture addresser's queue would hold its MFMAs too -- and this
+    // kernel has one wave per SIMD.
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int p = 0; p < 16; ++p)
+    for (int k4 = 0; k4 < 4; ++k4) {
 #pragma unroll
-      for (int qa = 0; qa < 2; ++qa)
+      for (int k = 3 * k4; k < 3 * k4 + 3; ++k) load_one(Pdx, Pdy, nxo, ndyo, k);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
-          acc[p][qa][qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(M[qa][p], V[qb][p], acc[p][qa][qb], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
+      for (int p = 4 * k4; p < 4 * k4 + 4; ++p)
+#pragma unroll
+        for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb)
+            acc[p][qa][qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(M[qa][p], V[qb][p], acc[p][qa][qb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   };
 
-  float dx0[2][16], dy0[2][4], dx1[2][16], dy1[2][4];
+  float dx0[2][16], dy0[2][4];
   if (total > 0) {
     int xo, dyo;
     item_off(0, xo, dyo);
     load_item(dx0, dy0, xo, dyo);
-    item_off(total > 1 ? 1 : 0, xo, dyo);
-    load_item(dx1, dy1, xo, dyo);
   }
-  int it = 0;
-  for (; it + 1 < total; it += 2) {           // set 0 holds the even items, set 1 the odd ones
-    step(dx0, dy0, it + 2);
-    step(dx1, dy1, it + 3);
-  }
-  if (it < total) step(dx0, dy0, it + 2);
+  for (int it = 0; it < total; ++it) step(dx0, dy0, it + 1);
 
   // ---- dg = G^T dU G per (cout, cin) -> this wave's image of the partial record in LDS
   // D register r of lane l: cout = 16*qa + 4*(l>>4) + r, cin = 16*qb + (l&15)
