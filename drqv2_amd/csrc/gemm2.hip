@@ -424,14 +424,26 @@ __global__ __launch_bounds__(256, 1) void trunk_wgrad_kernel(TWArgs g) {
     const int ibase = (t - t0) * KSTEPS;
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
-      loadb(b[(s + D) % NS], ibase + s + D);
-      __builtin_amdgcn_sched_barrier(0);
+      // the sixteen loads of the step three ahead go out one per MFMA (a burst would back up in the texture addresser
+      // and hold this wave's MFMAs behind it: one wave per SIMD)
+      unsigned lsoff, lld;
+      {
+        const int i = ibase + s + D, ic = i < total ? i : total - 1;
+        const int tt = t0 + ic / KSTEPS, st = ic % KSTEPS;
+        lsoff = (unsigned)tt * 128u + (unsigned)(st * 32) * ldb4;
+        lld = ldb4;
+      }
 #pragma unroll
       for (int e = 0; e < 16; e += 2) {
+        b[(s + D) % NS][e] = __uint_as_float(
+            __builtin_amdgcn_raw_buffer_load_b32(brs, bvoff, lsoff + (8 * (e >> 2) + (e & 3)) * lld, 0));
+        b[(s + D) % NS][e + 1] = __uint_as_float(
+            __builtin_amdgcn_raw_buffer_load_b32(brs, bvoff, lsoff + (8 * ((e + 1) >> 2) + ((e + 1) & 3)) * lld, 0));
+        __builtin_amdgcn_sched_barrier(0);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][e], b[s % NS][e], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][e + 1], b[s % NS][e + 1], acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
     const int n = t * 32 + col;
 #pragma unroll
