@@ -133,6 +133,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
     const int ty = rem / TH, tx = rem - ty * TH;
     return (((b * 32 + kk) * HIN + 2 * ty) * HIN + 2 * tx) * 4;
   };
+  auto load_patch_row = [&](float (&d)[16], int voff, int c, int i) {
+    if constexpr (ABL & 4) {
+      d[i * 4 + 0] = 1.0f + (float)(voff + c); d[i * 4 + 1] = 2.0f + (float)(voff + i);
+      d[i * 4 + 2] = 1.5f + (float)voff; d[i * 4 + 3] = (float)(c + i);
+      return;
+    }
+    const u32x4w v = __builtin_amdgcn_raw_buffer_load_b128(xrs, voff, c * (4 * PLANE) + i * (HIN * 4), 0);
+    const unsigned e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];
+    d[i * 4 + 0] = __uint_as_float(e0);
+    d[i * 4 + 1] = __uint_as_float(e1);
+    d[i * 4 + 2] = __uint_as_float(e2);
+    d[i * 4 + 3] = __uint_as_float(e3);
+  };
   auto load_patch = [&](float (&d)[16], int voff, int c) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -224,8 +237,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
         t[3 * 4 + j] = d[1 * 4 + j] - d[3 * 4 + j];
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (c + 1 < 8) load_patch(d, voff, c + 1);
-      else load_patch(d, nvoff, 0);
       load_A(A1, c, 1);
       __builtin_amdgcn_sched_barrier(0);
       float V[16];                           // (B^T d) B, all of it ahead of the MFMAs (no VALU->MFMA hazard per use)
@@ -243,6 +254,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
       auto half_step = [&](const f32x2w (&A)[8], int g) {
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
+          if (g == 0 && (p & 1) == 0) {
+            // the next patch (next k-step, or the next unit's first): one row ahead of every four MFMAs of the first
+            // half-step rather than four loads in a burst
+            __builtin_amdgcn_sched_barrier(0);
+            load_patch_row(d, c + 1 < 8 ? voff : nvoff, c + 1 < 8 ? c + 1 : 0, p >> 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
           const int pos = 8 * g + p;
           const f32x2w Ap = A[p];
           if (c == 0) {
