@@ -37,8 +37,10 @@ int g_ww_variant = 0;   // drq_dev_wgrad_wino_variant: timing ablations (tools/w
 #endif
 
 // ABL (development build only): 1 = no patch loads, 2 = no transforms (the raw patches are multiplied); wrong results
+// bx / nblk: the workgroup's index among the nblk workgroups that share this layer (a launch of its own: blockIdx.x /
+// gridDim.x; the three-layer launch below gives every layer a range of its grid)
 template <int HIN, int ABL = 0>
-__global__ __launch_bounds__(256, 1) void conv3x3_wgrad_wino_kernel(WWArgs a) {
+__device__ __forceinline__ void ww_body(const WWArgs& a, int bx, int nblk) {
 #pragma clang fp contract(off)
   constexpr int HOUT = HIN - 2;
   constexpr int TH = (HOUT + 1) / 2;          // tiles per row / tile rows per sample
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_wino_kernel(WWArgs a) {
   constexpr int TT = TH * TH;
   const int ntile = a.nb * TT;
   const int nstep = (ntile + 3) >> 2;
-  const int nw = (int)gridDim.x * 4, gw = (int)blockIdx.x * 4 + wid;
+  const int nw = nblk * 4, gw = bx * 4 + wid;
   const int total = gw < nstep ? (nstep - 1 - gw) / nw + 1 : 0;
 
   // per-lane byte offsets of this wave's it-th step: the x patch and the dY patch
@@ -261,13 +263,32 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_wino_kernel(WWArgs a) {
     }
   }
   __syncthreads();
-  float4* out = reinterpret_cast<float4*>(a.part + (long)blockIdx.x * PART);
+  float4* out = reinterpret_cast<float4*>(a.part + (long)bx * PART);
   const float4* r4 = reinterpret_cast<const float4*>(red);
   for (int i = threadIdx.x; i < PART / 4; i += 256) {
     const float4 p = r4[i], q = r4[PART / 4 + i], v = r4[2 * (PART / 4) + i], w = r4[3 * (PART / 4) + i];
     out[i] = make_float4((p.x + q.x) + (v.x + w.x), (p.y + q.y) + (v.y + w.y), (p.z + q.z) + (v.z + w.z),
                          (p.w + q.w) + (v.w + w.w));
   }
+}
+
+template <int HIN, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void conv3x3_wgrad_wino_kernel(WWArgs a) {
+  ww_body<HIN, ABL>(a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// The three 32->32 layers of the encoder backward in ONE launch: layer l owns workgroups [beg[l], beg[l+1]) of the
+// grid (shares proportional to its steps), every wave still accumulates one layer only and every workgroup writes one
+// record of its layer.  Two launches' worth of cold start, epilogue and tail less than three launches.
+struct WW3Args {
+  WWArgs l[3];        // HIN = 41, 39, 37 (conv2, conv3, conv4)
+  int beg[4];
+};
+__global__ __launch_bounds__(256, 1) void conv3x3_wgrad_wino3_kernel(WW3Args g) {
+  const int b = (int)blockIdx.x;
+  if (b < g.beg[1]) ww_body<41>(g.l[0], b, g.beg[1]);
+  else if (b < g.beg[2]) ww_body<39>(g.l[1], b - g.beg[1], g.beg[2] - g.beg[1]);
+  else ww_body<37>(g.l[2], b - g.beg[2], g.beg[3] - g.beg[2]);
 }
 
 template <int HIN>
@@ -311,6 +332,62 @@ int launch_ww(const WWArgs& a, int* nblocks, hipStream_t st) {
 #ifdef DRQ_DEV
 extern "C" DRQ_API void drq_dev_wgrad_wino_variant(int v) { g_ww_variant = v; }
 #endif
+
+// internal (step.hip): conv2, conv3, conv4 (hin 41, 39, 37) in one launch; x[l], dy[l], part[l] and the dY strides per
+// layer; nblocks[l] = records written for layer l
+int drq_conv3x3_wgrad_partial_wino3(const float* const* x, const float* const* dy, int nb, const long* dy_bs,
+                                    const long* dy_cs, const long* dy_rs, const long* dy_off, float* const* part,
+                                    size_t part_bytes, int* nblocks, hipStream_t st) {
+  if (!x || !dy || !dy_bs || !dy_cs || !dy_rs || !dy_off || !part || !nblocks || nb <= 0) return DRQ_EARG;
+  constexpr int PART = 9 * 1024 + 64;
+  const int hins[3] = {41, 39, 37};
+  WW3Args g{};
+  long steps[3], tot = 0;
+  for (int l = 0; l < 3; ++l) {
+    const int hin = hins[l], th = (hin - 1) / 2;
+    if (!x[l] || !dy[l] || !part[l] || ((size_t)part[l] & 15)) return DRQ_EARG;
+    const size_t xb = (size_t)nb * 32 * hin * hin * 4, dyb = (size_t)nb * dy_bs[l] * 4;
+    if (xb >= (1ull << 31) || dyb >= (1ull << 31) || dy_off[l] < 0 || dy_bs[l] <= 0) return DRQ_EARG;
+    g.l[l] = WWArgs{x[l], dy[l], (int)dy_bs[l], (int)dy_cs[l], (int)dy_rs[l], (int)dy_off[l], part[l], (unsigned)xb,
+                    (unsigned)dyb, nb};
+    steps[l] = ((long)nb * th * th + 3) / 4;
+    tot += steps[l];
+  }
+  const int cus = drq_num_cus();
+  if (cus < 3 || tot < 3L * 4) return DRQ_EARG;          // tiny problems: the caller launches the layers one by one
+  // workgroups per layer proportional to its steps (at least one each), all of them resident at once
+  int nb_l[3], used = 0;
+  for (int l = 0; l < 3; ++l) {
+    long n = (steps[l] * cus + tot / 2) / tot;
+    if (n < 1) n = 1;
+    if (n * 4 > steps[l]) n = (steps[l] + 3) / 4;
+    nb_l[l] = (int)n;
+    used += nb_l[l];
+  }
+  while (used > cus) {                                   // rounding overshoot: take from the largest share
+    int m = 0;
+    for (int l = 1; l < 3; ++l) if (nb_l[l] > nb_l[m]) m = l;
+    --nb_l[m]; --used;
+  }
+  g.beg[0] = 0;
+  for (int l = 0; l < 3; ++l) {
+    g.beg[l + 1] = g.beg[l] + nb_l[l];
+    nblocks[l] = nb_l[l];
+    if ((size_t)nb_l[l] * PART * sizeof(float) > part_bytes) return DRQ_EWS;
+  }
+  constexpr int lds = 4 * PART * 4;
+  static bool attr_dev[kMaxDevices] = {};
+  bool& attr = attr_dev[drq_device()];
+  if (!attr) {
+    const hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wgrad_wino3_kernel,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  hipLaunchKernelGGL(conv3x3_wgrad_wino3_kernel, dim3((unsigned)g.beg[3]), dim3(256), lds, st, g);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
 
 // internal (step.hip, conv.hip's public entry): partial records of the 32->32 weight gradient in Winograd form, same
 // record format and reduction as drq_conv3x3_wgrad_partial

@@ -77,6 +77,9 @@ int drq_conv3x3_wgrad_partial(const float* x, const float* dy, int nb, int cin, 
 // conv_wino_wgrad.hip (internal): the 32->32 layers' records in Winograd form (same format, same reduction)
 int drq_conv3x3_wgrad_partial_wino(const float* x, const float* dy, int nb, int hin, long dy_bs, long dy_cs, long dy_rs,
                                    long dy_off, float* part, size_t part_bytes, int* nblocks, hipStream_t st);
+int drq_conv3x3_wgrad_partial_wino3(const float* const* x, const float* const* dy, int nb, const long* dy_bs,
+                                    const long* dy_cs, const long* dy_rs, const long* dy_off, float* const* part,
+                                    size_t part_bytes, int* nblocks, hipStream_t st);
 int drq_conv3x3_wgrad_reduce_multi(int n, const float* const* part, const int* nblocks, const int* cin,
                                    float* const* dw, float* const* db, hipStream_t st);
 
@@ -545,20 +548,22 @@ int phase_conv_backward(const Ctx& c) {
   const float* parts[4];
   int nblk[4], cins[4];
   float *dws[4], *dbs[4];
+  // fp32: the input gradients first (a chain: dY4 -> dY3 -> dY2 -> dY1), then the weight gradients of conv2..4 in ONE
+  // Winograd launch (each needs only its layer's dY and input) and conv1's; bf16: layer by layer as before
+  const bool merged = !c.bf16();
   for (int l = 3; l >= 0; --l) {
     const int hin = kEncH[l], hout = kEncH[l + 1], hp = hout + 4;
     const float* dy = c.ws(dyid[l]);
     float* part = cws + (size_t)l * (quarter / sizeof(float));
-    if (c.bf16() && l > 0)
-      CK(drq_conv3x3_wgrad_partial_bf16(c.ws(actid[l]), dy, B, hin, 32L * hp * hp, (long)hp * hp, hp, 2L * hp + 2, part,
-                                        quarter, &nblk[l], st));
-    else if (l > 0)   // Winograd form (conv_wino_wgrad.hip); it reads dY's zero padding
-      CK(drq_conv3x3_wgrad_partial_wino(c.ws(actid[l]), dy, B, hin, 32L * hp * hp, (long)hp * hp, hp, 2L * hp + 2, part,
-                                        quarter, &nblk[l], st));
-    else
-    CK(drq_conv3x3_wgrad_partial(c.ws(actid[l]), dy, B, l == 0 ? C : 32, hin, l == 0 ? 2 : 1, 32L * hp * hp,
-                                 (long)hp * hp, hp, 2L * hp + 2, part, quarter, &nblk[l], st));
     parts[l] = part; cins[l] = l == 0 ? C : 32; dws[l] = c.g(P.enc_w[l]); dbs[l] = c.g(P.enc_b[l]);
+    if (!merged) {
+      if (l > 0)
+        CK(drq_conv3x3_wgrad_partial_bf16(c.ws(actid[l]), dy, B, hin, 32L * hp * hp, (long)hp * hp, hp, 2L * hp + 2, part,
+                                          quarter, &nblk[l], st));
+      else
+        CK(drq_conv3x3_wgrad_partial(c.ws(actid[l]), dy, B, C, hin, 2, 32L * hp * hp, (long)hp * hp, hp, 2L * hp + 2,
+                                     part, quarter, &nblk[l], st));
+    }
     if (l >= 1) {
       const int hpi = hin + 4;   // padded size of the next (shallower) gradient buffer
       void* const* ev = s->timing_events;
@@ -571,6 +576,29 @@ int phase_conv_backward(const Ctx& c) {
                                     c.ws(dyid[l - 1]), B, hout, 32L * hpi * hpi, (long)hpi * hpi, hpi, 2L * hpi + 2, st));
       if (ev && l == 2 && hipEventRecord((hipEvent_t)ev[3], st) != hipSuccess) return DRQ_EARG;
     }
+  }
+  if (merged) {
+    const float *xs[3], *dys[3];
+    float* ps[3];
+    long bs[3], cs[3], rs[3], off[3];
+    for (int k = 0; k < 3; ++k) {            // k = 0, 1, 2 -> layers 1, 2, 3 (conv2, conv3, conv4: hin 41, 39, 37)
+      const int l = k + 1, hp = kEncH[l + 1] + 4;
+      xs[k] = c.ws(actid[l]); dys[k] = c.ws(dyid[l]); ps[k] = const_cast<float*>(parts[l]);
+      bs[k] = 32L * hp * hp; cs[k] = (long)hp * hp; rs[k] = hp; off[k] = 2L * hp + 2;
+    }
+    int nb3[3];
+    int rc = drq_conv3x3_wgrad_partial_wino3(xs, dys, B, bs, cs, rs, off, ps, quarter, nb3, st);
+    if (rc == DRQ_EARG) {                    // tiny batch: one launch per layer
+      for (int k = 0; k < 3; ++k)
+        CK(drq_conv3x3_wgrad_partial_wino(xs[k], dys[k], B, kEncH[k + 1], bs[k], cs[k], rs[k], off[k], ps[k], quarter,
+                                          &nb3[k], st));
+    } else if (rc != 0) {
+      return rc;
+    }
+    for (int k = 0; k < 3; ++k) nblk[k + 1] = nb3[k];
+    const int hp0 = kEncH[1] + 4;
+    CK(drq_conv3x3_wgrad_partial(c.ws(actid[0]), c.ws(dyid[0]), B, C, kEncH[0], 2, 32L * hp0 * hp0, (long)hp0 * hp0, hp0,
+                                 2L * hp0 + 2, const_cast<float*>(parts[0]), quarter, &nblk[0], st));
   }
   CK(drq_conv3x3_wgrad_reduce_multi(4, parts, nblk, cins, dws, dbs, st));
   return 0;
