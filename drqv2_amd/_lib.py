@@ -57,6 +57,9 @@ PROTOTYPES = {
     "drq_gemm_batched_f32": (I, [I, P, L, I, P, L, I, P, L, I, I, I, P, I, P, I, P, I, I, I, P, SZ, P]),
     "drq_gemm_batched_bf16": (I, [I, P, L, I, P, L, I, P, L, I, I, I, P, I, P, I, P, I, I, P, SZ, P]),
     "drq_gemm_batched_partial": (I, [I, P, L, I, P, L, I, P, L, I, I, I, P, P, SZ, C.POINTER(I), P]),
+    "drq_mlp_fwd": (I, [I, P, L, P, L, P, L, I, I, I, P, I, P, P, C.POINTER(I), P]),
+    "drq_mlp_dgrad": (I, [I, P, L, P, L, P, L, I, I, I, P, I, P]),
+    "drq_mlp_wgrad_dgrad": (I, [I, P, L, P, L, P, P, P, L, P, L, P, I, I, I, I, P]),
     "drq_qout_fwd": (I, [I, P, P, P, P, I, I, P]),
     "drq_qout_bwd": (I, [I, P, P, P, P, P, P, I, I, P]),
     "drq_ln_tanh_fwd_multi": (I, [I, P, I, P, P, P, P, P, P, I, I, P]),
@@ -112,7 +115,7 @@ def load(dev=False):
         fn = getattr(lib, name)       # AttributeError = ABI mismatch, also loud
         fn.restype = res
         fn.argtypes = args
-    if lib.drq_abi_version() != 6:
+    if lib.drq_abi_version() != 7:
         raise DrqError("libdrqv2_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -305,3 +305,49 @@ def qout_bwd(dqs, hs, ws_, want_wgrad=True):
                            _ptr_array(dws) if dws else None, _ptr_array(dbs) if dbs else None, B, H, _stream()),
           "drq_qout_bwd")
     return dhs, dws, dbs
+
+
+def mlp_fwd(xs, ws_, bs, relu=True, qws=None):
+    """hidden-layer forward on the LDS-DMA ring kernel; qws: weight rows of a following Linear(N,1) -> partial dots.
+    Returns (list of y, list of qpart [M][nq] or None)."""
+    import ctypes
+    lib = _lib.load()
+    M, K = xs[0].shape
+    N = ws_[0].shape[0]
+    dev = xs[0].device
+    ys = [torch.empty((M, N), device=dev, dtype=torch.float32) for _ in xs]
+    qps = [torch.zeros((M, N // 32), device=dev, dtype=torch.float32) for _ in xs] if qws else None
+    nq = ctypes.c_int(0)
+    check(lib.drq_mlp_fwd(len(xs), _ptr_array(xs), xs[0].stride(0), _ptr_array(ws_), ws_[0].stride(0), _ptr_array(ys), N,
+                          M, N, K, _ptr_array(bs) if bs else None, int(relu), _ptr_array(qws) if qws else None,
+                          _ptr_array(qps) if qps else None, ctypes.byref(nq), _stream()), "drq_mlp_fwd")
+    if qps:
+        qps = [q.view(-1)[: M * nq.value].view(M, nq.value) for q in qps]
+    return ys, qps
+
+
+def mlp_dgrad(dys, ws_, masks=None):
+    lib = _lib.load()
+    M, K = dys[0].shape
+    N = ws_[0].shape[1]
+    dxs = [torch.empty((M, N), device=dys[0].device, dtype=torch.float32) for _ in dys]
+    check(lib.drq_mlp_dgrad(len(dys), _ptr_array(dys), dys[0].stride(0), _ptr_array(ws_), ws_[0].stride(0), _ptr_array(dxs),
+                            N, M, N, K, _ptr_array(masks) if masks else None, (masks[0].stride(0) if masks else 0),
+                            _stream()), "drq_mlp_dgrad")
+    return dxs
+
+
+def mlp_wgrad_dgrad(dys, xs, ws_, masks=None):
+    """both gradients of one hidden layer in one launch: returns (dws, dbs, dxs)."""
+    lib = _lib.load()
+    Brows, Nout = dys[0].shape
+    Kin = xs[0].shape[1]
+    dev = dys[0].device
+    dws = [torch.empty((Nout, Kin), device=dev, dtype=torch.float32) for _ in dys]
+    dbs = [torch.empty((Nout,), device=dev, dtype=torch.float32) for _ in dys]
+    dxs = [torch.empty((Brows, Kin), device=dev, dtype=torch.float32) for _ in dys]
+    check(lib.drq_mlp_wgrad_dgrad(len(dys), _ptr_array(dys), dys[0].stride(0), _ptr_array(xs), xs[0].stride(0),
+                                  _ptr_array(dws), _ptr_array(dbs), _ptr_array(ws_), ws_[0].stride(0), _ptr_array(dxs),
+                                  Kin, _ptr_array(masks) if masks else None, (masks[0].stride(0) if masks else 0),
+                                  Brows, Nout, Kin, _stream()), "drq_mlp_wgrad_dgrad")
+    return dws, dbs, dxs

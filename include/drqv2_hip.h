@@ -124,6 +124,26 @@ int drq_gemm_batched_partial(int nbatch, const float* const* A, long lda, int a_
                              int b_kc, float* const* C, long ldc, int M, int N, int K, const float* const* bias,
                              float* ws, size_t ws_bytes, int* splitk_out, drq_stream_t stream);
 
+/* ---- hidden layers of the policy / Q MLPs, nn.Linear(hidden, hidden)+ReLU (drqv2.py:77-81,103-111) on the LDS-DMA
+ * ring kernel (csrc/gemm3.hip): fp32, nbatch (<= 8) problems of one shape, every dimension a multiple of 64 (K of
+ * the forward / dgrad forms: of 32), 16-byte aligned operands, leading dimensions multiples of 4.  DRQ_EARG = shape
+ * not eligible (callers fall back to drq_gemm_batched_f32).
+ * drq_mlp_fwd: y_b [M][ldy] = relu?(x_b [M][ldx] w_b[N][ldw]^T + bias_b).  qw / qpart (both or neither): the weight
+ * row [N] of a FOLLOWING Linear(N, 1) (the Q heads' output layer, drqv2.py:106,111): qpart_b [M][*nq_out] receives the
+ * partial dots  sum_{n in column tile j} y_b[m][n] qw_b[n];  that layer's output is their sum in index order + bias.
+ * drq_mlp_dgrad: dx_b [M][lddx] = (dy_b [M][lddy] w_b [K][ldw]) * (mask_b [M][ldmask] > 0)?   (N columns).
+ * drq_mlp_wgrad_dgrad: both gradients of one layer in ONE launch: dw_b [Nout][Kin] = dy_b^T x_b, db_b [Nout] =
+ * column sums of dy_b (db may be NULL), dx_b [Brows][lddx] = (dy_b w_b [Nout][ldw]) * (mask_b > 0)?. */
+int drq_mlp_fwd(int nbatch, const float* const* x, long ldx, const float* const* w, long ldw, float* const* y,
+                long ldy, int M, int N, int K, const float* const* bias, int relu, const float* const* qw,
+                float* const* qpart, int* nq_out, drq_stream_t stream);
+int drq_mlp_dgrad(int nbatch, const float* const* dy, long lddy, const float* const* w, long ldw, float* const* dx,
+                  long lddx, int M, int N, int K, const float* const* mask, int ldmask, drq_stream_t stream);
+int drq_mlp_wgrad_dgrad(int nbatch, const float* const* dy, long lddy, const float* const* x, long ldx,
+                        float* const* dw, float* const* db, const float* const* w, long ldw, float* const* dx,
+                        long lddx, const float* const* mask, int ldmask, int Brows, int Nout, int Kin,
+                        drq_stream_t stream);
+
 /* ---- output layer of the Q heads, nn.Linear(hidden, 1) (drqv2.py:106,111), nz (<= 8) problems per launch:
  * q = h w^T + b;  backward: dh = (dq w) * (h > 0), and if dw/db are given dw = dq^T h, db = sum dq. */
 int drq_qout_fwd(int nz, const float* const* h, const float* const* w, const float* const* b, float* const* q, int B,

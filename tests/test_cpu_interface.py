@@ -200,7 +200,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert set(_lib.PROTOTYPES) == declared
-    assert lib.drq_abi_version() == 6
+    assert lib.drq_abi_version() == 7
     # ... and the other direction: the product library exports NOTHING named drq* beyond the header (internal helpers
     # have hidden visibility; the development hooks drq_dev_* exist only in the -DDRQ_DEV build of tools/)
     import subprocess
