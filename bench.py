@@ -93,7 +93,8 @@ def parse_args(argv=None):
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script as child processes.  The parent
     has not touched (and never touches) the GPU; it does not re-exec itself.  Rank 0's stdout (the JSON line) is
-    relayed; the exit code is the first non-zero child code."""
+    relayed; the exit code is the first non-zero child code (the other ranks are then stopped), 124 after
+    DRQ_BENCH_RANK_TIMEOUT_S seconds."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -105,12 +106,51 @@ def launch_ranks(args):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        p.wait()
-        rc = rc or p.returncode
-    sys.stdout.write(out.decode())
+    # supervise: the first rank that fails takes the others with it (a survivor would sit in init_process_group or a
+    # collective until the RCCL / gloo timeout); SIGTERM / SIGINT to the parent reach the children; the whole run is bounded
+    import signal
+    import threading
+
+    def kill_all(*_):
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.monotonic() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+
+    old_handlers = {sig: signal.signal(sig, lambda *_: (kill_all(), sys.exit(128 + sig))) for sig in (signal.SIGTERM, signal.SIGINT)}
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    limit = float(os.environ.get("DRQ_BENCH_RANK_TIMEOUT_S", "1500"))
+    t_end = time.monotonic() + limit
+    rc = 0
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                rc = bad[0]
+                print(f"bench.py: a rank exited with code {rc}; stopping the other ranks", file=sys.stderr)
+                kill_all()
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() > t_end:
+                print(f"bench.py: ranks still running after {limit:.0f} s; stopping them", file=sys.stderr)
+                kill_all()
+                rc = 124
+                break
+            time.sleep(0.05)
+    finally:
+        for sig, h in old_handlers.items():
+            signal.signal(sig, h)
+    reader.join(timeout=5.0)
+    sys.stdout.write(b"".join(c for c in chunks if c).decode())
     sys.stdout.flush()
     return rc
 

@@ -292,16 +292,23 @@ class DrQV2Agent:
     def import_reference_state(self, st):
         """The reverse: weights, target and Adam state from `export_reference_state()`-shaped data, e.g. what a
         reference agent produces with {name: module.state_dict()} and {name: optimiser.state_dict()}."""
+        # data parallel: the deferred Adam(encoder/actor) of the last update must land BEFORE the imported weights do
+        self._engine.flush()
         for n in ("encoder", "actor", "critic", "critic_target"):
             getattr(self, n).load_state_dict(st[n])
         eng = self._engine
-        for net, opt_name in (("enc", "encoder_opt"), ("actor", "actor_opt"), ("critic", "critic_opt")):
+        for net, opt_name, mod in (("enc", "encoder_opt", self.encoder), ("actor", "actor_opt", self.actor),
+                                   ("critic", "critic_opt", self.critic)):
             mine = getattr(self, opt_name)
             ref = st[opt_name]["state"]
             t = 0
-            for i, off in enumerate(eng.layout[net]):
+            for i, (p, off) in enumerate(zip(mod.parameters(), eng.layout[net])):
                 ent = ref.get(i, ref.get(str(i)))
                 if ent is None:
+                    # no state for this parameter in the reference optimiser (it has not stepped): fresh moments, not
+                    # whatever this agent had accumulated (bias correction restarts at t = 0)
+                    eng.adam_m[off:off + p.numel()].zero_()
+                    eng.adam_v[off:off + p.numel()].zero_()
                     continue
                 m, v = ent["exp_avg"], ent["exp_avg_sq"]
                 eng.adam_m[off:off + m.numel()].copy_(m.reshape(-1))

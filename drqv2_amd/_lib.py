@@ -31,6 +31,8 @@ class DrqStep(C.Structure):
         ("store_aug_next", C.c_int),
         ("bf16", C.c_int),
         ("timing_events", C.POINTER(C.c_void_p)),
+        ("timing_n", C.c_int),
+        ("flags", C.c_int),
     ]
 
 
@@ -60,6 +62,8 @@ PROTOTYPES = {
     "drq_mlp_fwd": (I, [I, P, L, P, L, P, L, I, I, I, P, I, P, P, C.POINTER(I), P]),
     "drq_mlp_dgrad": (I, [I, P, L, P, L, P, L, I, I, I, P, I, P]),
     "drq_mlp_wgrad_dgrad": (I, [I, P, L, P, L, P, P, P, L, P, L, P, I, I, I, I, P]),
+    "drq_ln_l1_fwd": (I, [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, L, P]),
+    "drq_policy_out_l1_fwd": (I, [P, P, P, P, I, I, I, I, I, F, F, I, P, P, P, L, P, P, P, L, I, P, P, P, P]),
     "drq_qout_fwd": (I, [I, P, P, P, P, I, I, P]),
     "drq_qout_bwd": (I, [I, P, P, P, P, P, P, I, I, P]),
     "drq_ln_tanh_fwd_multi": (I, [I, P, I, P, P, P, P, P, P, I, I, P]),

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdrqv2_hip.so")
 LIB_DEV = os.path.join(HERE, "libdrqv2_hip_dev.so")
-SOURCES = ["conv.hip", "conv_wino.hip", "conv_wino_wgrad.hip", "conv1aug.hip", "conv_bf16.hip", "gemm.hip", "gemm2.hip", "gemm3.hip", "skinny.hip", "elementwise.hip", "rng.hip", "step.hip"]
+SOURCES = ["conv.hip", "conv_wino.hip", "conv_wino_wgrad.hip", "conv1aug.hip", "conv_bf16.hip", "gemm.hip", "gemm2.hip", "gemm3.hip", "rowblock.hip", "skinny.hip", "elementwise.hip", "rng.hip", "step.hip"]
 # per-file additions.  conv_wino.hip: hipcc's SLP vectoriser packs the transform adds into v_pk_add_f32 plus the
 # v_mov shuffles that feed them -- more VALU issue slots beside the MFMAs, not fewer (136 moves per unit)
 # rng.hip: hipRAND's Box-Muller (logf, sincosf, the scaling multiply-adds) must round like the copy inside torch's

@@ -397,6 +397,13 @@ int drq_conv3x3_wgrad_partial_wino(const float* x, const float* dy, int nb, int 
   const size_t xb = (size_t)nb * 32 * hin * hin * 4;
   const size_t dyb = (size_t)nb * dy_bs * 4;
   if (xb >= (1ull << 31) || dyb >= (1ull << 31) || dy_off < 0 || dy_bs <= 0) return DRQ_EARG;
+  // The kernel reads row and column `hout` of every dy plane as the empty half of the last 2x2 tile: dy must be the
+  // interior of a zero-padded buffer (one more zero row and column at least), as the update stores its gradients.  A
+  // contiguous [nb][32][hout][hout] dy would silently wrap into the next row / plane: refused.
+  {
+    const int hout = hin - 2;
+    if (dy_rs < hout + 1 || dy_cs < (long)(hout + 1) * dy_rs) return DRQ_EARG;
+  }
   if ((size_t)drq_num_cus() * (9 * 1024 + 64) * sizeof(float) > part_bytes) return DRQ_EWS;
   if (((size_t)part & 15) != 0) return DRQ_EARG;
   WWArgs a{x, dy, (int)dy_bs, (int)dy_cs, (int)dy_rs, (int)dy_off, part, (unsigned)xb, (unsigned)dyb, nb};

@@ -73,6 +73,17 @@ int drq_gemm3_dgrad(int nbatch, const float* const* dy, long lddy, const float* 
 int drq_gemm3_wgrad_dgrad(int nbatch, const float* const* dy, long lddy, const float* const* x, long ldx,
                           float* const* dw, float* const* db, const float* const* w, long ldw, float* const* dx,
                           long lddx, const float* const* mask, int ldmask, int Brows, int Nout, int Kin, hipStream_t st);
+// rowblock.hip (internal): LayerNorm+tanh fused with the first MLP layers; policy output layer + sample fused with the
+// target critic's first layers (DRQ_EARG = shape not eligible)
+int drq_lnl1_fwd(int njobs, const float* const* part, const float* const* z, const float* const* bias,
+                 const float* const* gamma, const float* const* beta, float* const* out, const int* ldo,
+                 float* const* xhat, float* const* rstd, const float* const* tail, const int* tail_ld, const int* tail_n,
+                 const int* rows, const int* nheads, const float* const* w, const float* const* b, float* const* y, int F,
+                 int H, int splitk, long slab, hipStream_t st);
+int drq_polout_l1_fwd(const float* p2, const float* w3, const float* b3, float* p3, int rows, int srow0, int H, int A,
+                      int F, float std, float clip, int use_clip, const float* noise_hi, float* mu_hi, float* ha_hi,
+                      long lda_hi, const float* noise_lo, float* mu_lo, float* ha_lo, long lda_lo, int nheads,
+                      const float* const* w, const float* const* b, float* const* y, hipStream_t st);
 // conv_bf16.hip (internal)
 int drq_conv3x3_wgrad_partial_bf16(const float* x, const float* dy, int nb, int hin, long dy_bs, long dy_cs, long dy_rs,
                                    long dy_off, float* part, size_t part_bytes, int* nblocks, hipStream_t st);
@@ -259,6 +270,22 @@ struct Ctx {
   bool actor_loss_fused() const {
     return fuse_actor_loss && ((size_t)s->B + 5 * 1024 + 16) * 4 <= 60 * 1024;
   }
+  // row-local stages fused with the first MLP layers (rowblock.hip): fp32, shapes its kernels take
+  bool fuse_rows() const {
+    // measured (tools/ab_flags.py, same process, interleaved): cheetah_run B=256 1021.9 us fused against 1024.2, but
+    // humanoid_run (F+A = 121: odd, dword weight loads, 128-long padded reduction) 540 against 508 us at B=32 and 1220
+    // against 1203 at B=256 -- the fused kernels are chains of dependent memory round trips like the launches they
+    // replace, and only win where every weight row can be fetched with 8- or 16-byte loads into a 64-long reduction
+    return !(s->flags & DRQ_STEP_NO_ROW_FUSION) && !s->bf16 && s->A <= 32 && s->F + s->A <= 64 && s->F % 2 == 0 &&
+           s->A % 2 == 0 && s->H % 256 == 0;
+  }
+  bool use_gemm3() const { return !(s->flags & DRQ_STEP_NO_GEMM3) && !s->bf16; }
+  // timing pair k of DrqStep.timing_events (bench.py's roofline), recorded when the host asked for that many
+  int stamp(int idx) const {
+    if (s->timing_events && idx < s->timing_n && hipEventRecord((hipEvent_t)s->timing_events[idx], st) != hipSuccess)
+      return DRQ_EARG;
+    return 0;
+  }
   float* ws(int id) const { return s->ws + W.off[id]; }
   float* p(long off) const { return s->params + off; }
   float* g(long off) const { return s->grads + off; }
@@ -277,7 +304,7 @@ struct Ctx {
             int M, int Nout, int K, const float* const* mask, int ldmask) const {
     // two or more hidden x hidden problems: the LDS-DMA ring kernel (measured 15.8 against 19.2 us for the two heads of
     // the actor update; one problem of 2B rows: the LDS-free kernel is as fast)
-    if (!bf16() && n >= 2 && K >= 256 && Nout >= 256) {
+    if (use_gemm3() && n >= 2 && K >= 256 && Nout >= 256) {
       const int rc = drq_gemm3_dgrad(n, dy, lddy, w, ldw, dx, lddx, M, Nout, K, mask, ldmask, st);
       if (rc != DRQ_EARG) return rc;
     }
@@ -314,7 +341,7 @@ struct Ctx {
   int wgrad_dgrad(int n, const float* const* dy, long lddy, const float* const* x, long ldx, float* const* dw,
                   float* const* db, const float* const* w, long ldw, float* const* dx, long lddx,
                   const float* const* mask, int ldmask, int Brows, int N, int K) const {
-    if (!bf16() && n >= 2) {       // both heads of the critic: the LDS-DMA ring kernel (25.5 against 32.6 us)
+    if (use_gemm3() && n >= 2) {   // both heads of the critic: the LDS-DMA ring kernel (25.5 against 32.6 us)
       const int rc = drq_gemm3_wgrad_dgrad(n, dy, lddy, x, ldx, dw, db, w, ldw, dx, lddx, mask, ldmask, Brows, N, K, st);
       if (rc != DRQ_EARG) return rc;
     }
@@ -334,7 +361,7 @@ int encoder_forward(const Ctx& c, const float* x, int nb, float* a1, float* a2, 
   const ParamLayout& P = c.P;
   float* outs[4] = {a1, a2, a3, a4};
   const float* in = x ? x : a1;
-  void* const* ev = timed ? c.s->timing_events : nullptr;
+  void* const* ev = (timed && c.s->timing_n >= 2) ? c.s->timing_events : nullptr;
   for (int l = x ? 0 : 1; l < 4; ++l) {
     const int hin = kEncH[l], hout = kEncH[l + 1];
     if (ev && l == 1 && hipEventRecord((hipEvent_t)ev[0], c.st) != hipSuccess) return DRQ_EARG;
@@ -388,8 +415,9 @@ int policy_forward(const Ctx& c, const float* h, int rows, float* p1, float* p2,
 }
 
 // Twin-Q forward for `nn` (net, input) pairs at once: 2*nn problems per layer (drqv2.py:103-111,117-119)
+// l1_done: the first layers' outputs are already in h1 (fused with the row-local stage that produced their input)
 int q_forward(const Ctx& c, int nn, const HeadOff* const* nets, const float* const* ha, float* const* h1,
-              float* const* h2, float* const* q) {
+              float* const* h2, float* const* q, bool l1_done = false) {
   const DrqStep* s = c.s;
   const int B = s->B, H = s->H, FA = s->F + s->A;
   const long BH = (long)B * H;
@@ -406,7 +434,7 @@ int q_forward(const Ctx& c, int nn, const HeadOff* const* nets, const float* con
         y2[z] = h2[i] + h * BH; hh2[z] = y2[z];
         qq[z] = q[i] + h * B;
       }
-    if (l == 0) CK(c.fwd(2 * nn, x, FA, w, b, y1, H, B, H, FA, 1));
+    if (l == 0 && !l1_done) CK(c.fwd(2 * nn, x, FA, w, b, y1, H, B, H, FA, 1));
     if (l == 1) CK(c.fwd(2 * nn, hh1, H, w, b, y2, H, B, H, H, 1));
     if (l == 2) CK(drq_qout_fwd(2 * nn, hh2, w, b, qq, B, H, c.st));
   }
@@ -450,6 +478,7 @@ int phase_critic_heads(const Ctx& c) {
   // only by the actor step; the actor's weights do not change before that, so it is evaluated here.
   float* z4 = c.ws(W_Z4);
   float* hrows = c.ws(W_HROWS);        // actor trunk outputs: rows [0,B) obs, [B,2B) next
+  bool rows_fused = false;
   {
     const float* x[4] = {feat_obs, feat_obs, feat_next, feat_next};
     const float* w[4] = {c.p(cr.trunk_w), c.p(ac.trunk_w), c.p(ac.trunk_w), c.p(tg.trunk_w)};
@@ -469,21 +498,54 @@ int phase_critic_heads(const Ctx& c) {
     const float* tail[4] = {s->action, nullptr, nullptr, nullptr};
     const int tld[4] = {A, 0, 0, 0};
     const bool with_tail = A <= 64;
+    if (c.fuse_rows() && sk > 1) {
+      // ... and the first layers ride along with the LayerNorm: both Q heads of the critic on [h, action], the policy's
+      // first layer on the actor's 2B rows (rowblock.hip; one launch instead of three)
+      const float* part[4];
+      for (int g = 0; g < 4; ++g) part[g] = c.gemm_ws() + (long)g * sk * B * F;
+      const int tn[4] = {A, 0, 0, 0};
+      const int rows[4] = {B, B, B, B};
+      const int nheads[4] = {2, 1, 1, 0};
+      const float* w1[8] = {c.p(cr.w[0][0]), c.p(cr.w[1][0]), c.p(ac.w[0][0]), nullptr, c.p(ac.w[0][0]), nullptr, nullptr, nullptr};
+      const float* b1[8] = {c.p(cr.b[0][0]), c.p(cr.b[1][0]), c.p(ac.b[0][0]), nullptr, c.p(ac.b[0][0]), nullptr, nullptr, nullptr};
+      float* y1[8] = {c.ws(W_C1), c.ws(W_C1) + BH, c.ws(W_P1), nullptr, c.ws(W_P1) + BH, nullptr, nullptr, nullptr};
+      const int rc = drq_lnl1_fwd(4, part, nullptr, b, gm, bt, out, ldo, xh, rs, tail, tld, tn, rows, nheads, w1, b1, y1, F, H, sk,
+                                  (long)B * F, st);
+      if (rc == DRQ_OK) rows_fused = true;
+      else if (rc != DRQ_EARG) return rc;
+    }
+    if (!rows_fused) {
     CK(drq_ln_tanh_fwd_multi_part(4, zz, F, gm, bt, out, ldo, xh, rs, B, F, with_tail ? tail : nullptr,
                                   with_tail ? tld : nullptr, with_tail ? A : 0, sk > 1 ? c.gemm_ws() : nullptr, b, sk,
                                   st));
     if (!with_tail) CK(drq_copy_cols(s->action, A, c.ws(W_HA_C) + F, FA, B, A, st));
+    }
   }
   // policy MLP once on the 2B stacked rows
   // ... and, in the output-layer kernel, a' ~ TruncN(actor(next)) for the target (:180-183)
   // ... and the actor update's own draw for the obs rows (:210-211; same policy output, the actor's weights do
   // not change in between): mu and the action columns of the second critic input are ready for phase 6
+  bool q_l1_done = false;
+  if (rows_fused) {
+    const float *x1[1] = {c.ws(W_P1)}, *w1[1] = {c.p(ac.w[0][1])}, *b1[1] = {c.p(ac.b[0][1])};
+    float* y1[1] = {c.ws(W_P2)};
+    CK(c.fwd(1, x1, H, w1, b1, y1, H, 2 * B, H, H, 1));
+    // output layer + both samples + the target critic's first layers on [h_target, a'] in one launch
+    const float* wt[2] = {c.p(tg.w[0][0]), c.p(tg.w[1][0])};
+    const float* bt2[2] = {c.p(tg.b[0][0]), c.p(tg.b[1][0])};
+    float* yt[2] = {c.ws(W_T1), c.ws(W_T1) + BH};
+    CK(drq_polout_l1_fwd(c.ws(W_P2), c.p(ac.w[0][2]), c.p(ac.b[0][2]), c.ws(W_P3), 2 * B, B, H, A, F, s->std, s->clip, 1,
+                         s->noise_critic, nullptr, c.ws(W_HA_T), FA, s->noise_actor, c.ws(W_MU_O), c.ws(W_HA_C2), FA, 2, wt,
+                         bt2, yt, st));
+    q_l1_done = true;
+  } else {
   bool did0 = false;
   CK(policy_forward(c, hrows, 2 * B, c.ws(W_P1), c.ws(W_P2), c.ws(W_P3), B, s->noise_critic, c.ws(W_HA_T) + F, FA,
                     s->noise_actor, c.ws(W_MU_O), c.ws(W_HA_C2) + F, FA, &did0));
   if (!did0)
     CK(drq_trunc_normal_sample(c.ws(W_P3), s->noise_actor, s->std, s->clip, 1, c.ws(W_MU_O), c.ws(W_HA_C2) + F, FA, B,
                                A, st));
+  }
 
   // y = r + d*min Q_target(next, a')   (:184-186);  critic(obs, action) (:188)
   {
@@ -492,7 +554,7 @@ int phase_critic_heads(const Ctx& c) {
     float* h1[2] = {c.ws(W_T1), c.ws(W_C1)};
     float* h2[2] = {c.ws(W_T2), c.ws(W_C2)};
     float* q[2] = {c.ws(W_TQ), c.ws(W_Q)};
-    CK(q_forward(c, 2, nets, ha, h1, h2, q));
+    CK(q_forward(c, 2, nets, ha, h1, h2, q, q_l1_done));
   }
   const float invB = 1.0f / (float)s->global_B;
 
@@ -582,7 +644,7 @@ int phase_conv_backward(const Ctx& c) {
     }
     if (l >= 1) {
       const int hpi = hin + 4;   // padded size of the next (shallower) gradient buffer
-      void* const* ev = s->timing_events;
+      void* const* ev = s->timing_n >= 4 ? s->timing_events : nullptr;
       if (ev && l == 2 && hipEventRecord((hipEvent_t)ev[2], st) != hipSuccess) return DRQ_EARG;
       if (c.bf16())
         CK(drq_conv3x3_dgrad_bf16(dy, c.p(P.enc_w[l]), c.ws(actid[l]), c.ws(dyid[l - 1]), B, hout, 32L * hpi * hpi,
@@ -603,6 +665,7 @@ int phase_conv_backward(const Ctx& c) {
       bs[k] = 32L * hp * hp; cs[k] = (long)hp * hp; rs[k] = hp; off[k] = 2L * hp + 2;
     }
     int nb3[3];
+    CK(c.stamp(4));
     int rc = drq_conv3x3_wgrad_partial_wino3(xs, dys, B, bs, cs, rs, off, ps, quarter, nb3, st);
     if (rc == DRQ_EARG) {                    // tiny batch: one launch per layer
       for (int k = 0; k < 3; ++k)
@@ -611,6 +674,7 @@ int phase_conv_backward(const Ctx& c) {
     } else if (rc != 0) {
       return rc;
     }
+    CK(c.stamp(5));
     for (int k = 0; k < 3; ++k) nblk[k + 1] = nb3[k];
     const int hp0 = kEncH[1] + 4;
     CK(drq_conv3x3_wgrad_partial(c.ws(actid[0]), c.ws(dyid[0]), B, C, kEncH[0], 2, 32L * hp0 * hp0, (long)hp0 * hp0, hp0,
@@ -651,6 +715,8 @@ int phase_actor_forward(const Ctx& c) {
 
   CK(drq_adam_flat(c.p(P.seg[2]), c.g(P.seg[2]), s->adam_m + P.seg[2], s->adam_v + P.seg[2], P.seg[3] - P.seg[2],
                    s->lr, s->step_critic, s->gscale, c.p(P.seg[6]), s->tau, st));
+  bool q_l1_done = false;
+  CK(c.stamp(8));
 
   // a ~ TruncN(actor(obs.detach())) (:210-211) was drawn in phase 4 together with the policy output
   // updated critic on (obs, a) (:213)
@@ -662,6 +728,21 @@ int phase_actor_forward(const Ctx& c) {
     const float *zz[1] = {y[0]}, *gm[1] = {c.p(cr.ln_g)}, *bt[1] = {c.p(cr.ln_b)};
     float* out[1] = {c.ws(W_HA_C2)};
     const int ldo[1] = {FA};
+    if (c.fuse_rows() && sk > 1) {
+      // LayerNorm + both first layers of the (updated) critic on [h, a]: a already sits in the action columns of the
+      // row (phase 4 drew it), the "tail" is those columns themselves
+      const float* part[1] = {c.gemm_ws()};
+      const float* tail[1] = {c.ws(W_HA_C2) + F};
+      const int tld[1] = {FA}, tn[1] = {A}, rows[1] = {B}, nheads[1] = {2};
+      const float* w1[2] = {c.p(cr.w[0][0]), c.p(cr.w[1][0])};
+      const float* b1[2] = {c.p(cr.b[0][0]), c.p(cr.b[1][0])};
+      float* y1[2] = {c.ws(W_T1), c.ws(W_T1) + (long)B * s->H};
+      const int rc = drq_lnl1_fwd(1, part, nullptr, b, gm, bt, out, ldo, nullptr, nullptr, tail, tld, tn, rows, nheads, w1, b1,
+                                  y1, F, s->H, sk, (long)B * F, st);
+      if (rc == DRQ_OK) q_l1_done = true;
+      else if (rc != DRQ_EARG) return rc;
+    }
+    if (!q_l1_done)
     CK(drq_ln_tanh_fwd_multi_part(1, zz, F, gm, bt, out, ldo, nullptr, nullptr, B, F, nullptr, nullptr, 0,
                                   sk > 1 ? c.gemm_ws() : nullptr, b, sk, st));
   }
@@ -669,7 +750,7 @@ int phase_actor_forward(const Ctx& c) {
     const HeadOff* nets[1] = {&cr};
     const float* ha[1] = {c.ws(W_HA_C2)};
     float *h1[1] = {c.ws(W_T1)}, *h2[1] = {c.ws(W_T2)}, *q[1] = {c.ws(W_TQ)};
-    CK(q_forward(c, 1, nets, ha, h1, h2, q));
+    CK(q_forward(c, 1, nets, ha, h1, h2, q, q_l1_done));
   }
   const float invB = 1.0f / (float)s->global_B;
   // the loss kernel also publishes the eight sums to the host mirror when one is given
@@ -809,10 +890,17 @@ DRQ_API int drq_update_phase(const DrqStep* s, int phase) {
   if (phase < -1 || phase > 9) return DRQ_EARG;
   c.fuse_actor_loss = phase == -1 || phase == 1;
   if (phase == 3 || phase == 0 || phase == -1) CK(phase_encode(c));
-  if (phase == 4 || phase == 0 || phase == -1) CK(phase_critic_heads(c));
+  if (phase == 4 || phase == 0 || phase == -1) {
+    CK(c.stamp(6));
+    CK(phase_critic_heads(c));
+    CK(c.stamp(7));
+  }
   if (phase == 5 || phase == 0 || phase == -1) CK(phase_conv_backward(c));
   if (phase == 6 || phase == 1 || phase == -1) CK(phase_actor_forward(c));
-  if (phase == 7 || phase == 1 || phase == -1) CK(phase_actor_backward(c));
+  if (phase == 7 || phase == 1 || phase == -1) {
+    CK(phase_actor_backward(c));
+    CK(c.stamp(9));
+  }
   if (phase == 2 || phase == -1) {          // both optimiser steps in one launch
     const ParamLayout& P = c.P;
     CK(drq_adam_flat2(c.p(P.seg[0]), c.g(P.seg[0]), s->adam_m + P.seg[0], s->adam_v + P.seg[0], P.seg[1] - P.seg[0],

@@ -197,6 +197,10 @@ class _Done:
 
 
 class StepEngine:
+    # rows per GPU and update: the Winograd / fused aug+conv1 kernels use 32-bit byte offsets into the first layer's
+    # output [2B][32][41][41] fp32, < 2^31 bytes (conv_wino.hip: DRQ_EARG beyond); parity is pinned up to 2048 rows
+    MAX_BATCH = 4096
+
     def __init__(self, encoder, actor, critic, critic_target, obs_shape, action_dim, feature_dim, hidden_dim, lr,
                  device):
         self.device = torch.device(device)
@@ -237,7 +241,9 @@ class StepEngine:
         self._pending = None      # (all-reduce handle, descriptor, tensors kept alive) of a deferred Adam(actor)
         self._pending_enc = None  # the same for Adam(encoder)
         self.global_metrics = False   # data parallel: all-reduce the metric sums (else: this rank's shard)
-        self._timing_array = None # ctypes array of 4 hipEvent_t (set_timing_events)
+        self._timing_array = None # ctypes array of hipEvent_t (set_timing_events)
+        self._timing_n = 0
+        self.step_flags = 0       # DrqStep.flags: 1 = no row fusion, 2 = no gemm3 (A/B measurements, both-form tests)
         self._side = None         # side stream of the metric-sums exchange
         self._side_busy = False
         self.bf16 = False             # DrqStep.bf16: the update's convs / GEMMs on the bf16 MFMA (set_compute_dtype)
@@ -316,13 +322,14 @@ class StepEngine:
         return self.exchange.start(t)
 
     def set_timing_events(self, events):
-        """bench.py instrumentation: 4 torch.cuda.Event(enable_timing=True), each recorded once already (so that
-        torch has created the hipEvent_t), or None.  See DrqStep.timing_events."""
+        """bench.py instrumentation: 4..10 torch.cuda.Event(enable_timing=True) (pairs), each recorded once already (so
+        that torch has created the hipEvent_t), or None.  See DrqStep.timing_events."""
         if events is None:
             self._timing_array = None
             return
-        arr = (ctypes.c_void_p * 4)(*[int(e.cuda_event) for e in events])
+        arr = (ctypes.c_void_p * len(events))(*[int(e.cuda_event) for e in events])
         self._timing_array = arr
+        self._timing_n = len(events)
 
     # ---- the update's random draws ----------------------------------------------------------
     def _rng_launch(self, gen, n, A, pad_range, with_noise):
@@ -442,7 +449,9 @@ class StepEngine:
         d.sums_host = ptr(self.sums_host) if (self.pg is None and self.sums_host is not None) else None
         d.store_aug_next = int(self.store_aug_next)
         d.bf16 = int(self.bf16)
-        d.timing_events = self._timing_array      # None, or 4 hipEvent_t for bench.py's roofline
+        d.timing_events = self._timing_array      # None, or hipEvent_t pairs for bench.py's roofline
+        d.timing_n = self._timing_n if self._timing_array is not None else 0
+        d.flags = int(self.step_flags)
         return d
 
     def update(self, obs, action, reward, discount, next_obs, shift_obs, shift_next, noise_critic, noise_actor, std,
@@ -453,6 +462,10 @@ class StepEngine:
             if t.dtype != torch.uint8 or tuple(t.shape) != (B, self.C, 84, 84) or not t.is_contiguous():
                 raise _lib.DrqError(f"update(): {nm} must be contiguous uint8 [{B},{self.C},84,84] "
                                     f"(replay_buffer.py:185-189), got {t.dtype} {tuple(t.shape)}")
+        if B > self.MAX_BATCH:
+            raise _lib.DrqError(f"update(): batch of {B} rows per GPU; the fp32 encoder kernels address an activation "
+                                f"buffer with 32-bit byte offsets, which holds up to {self.MAX_BATCH} rows "
+                                "(2B x 32 x 41 x 41 floats < 2 GiB): split the batch over more GPUs")
         B_global = B * self.world if B_global is None else B_global
         steps = (self.critic_opt.begin_step(), self.encoder_opt.begin_step(), self.actor_opt.begin_step())
         d = self.make_desc(B, B_global, std, clip, tau, steps)

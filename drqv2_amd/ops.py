@@ -351,3 +351,61 @@ def mlp_wgrad_dgrad(dys, xs, ws_, masks=None):
                                   Kin, _ptr_array(masks) if masks else None, (masks[0].stride(0) if masks else 0),
                                   Brows, Nout, Kin, _stream()), "drq_mlp_wgrad_dgrad")
     return dws, dbs, dxs
+
+
+def _int_array(vals):
+    import ctypes
+    return (ctypes.c_int * len(vals))(*vals)
+
+
+def ln_l1_fwd(jobs, F, H, splitk=0, slab=0):
+    """jobs: list of dicts with keys z or part (+bias), gamma, beta, rows, optional tail [rows][A], save (bool),
+    heads: list of (w [H][K], b [H]).  Returns per job dict(out [rows][F+tail_n], xhat, rstd, ys=[...])."""
+    lib = _lib.load()
+    dev = jobs[0]["gamma"].device
+    res, part, z, bias, gamma, beta, out, ldo, xhat, rstd, tail, tld, tn, rows, nh, w, b, y = ([] for _ in range(18))
+    for j in jobs:
+        r = j["rows"]
+        t = j.get("tail")
+        n_t = t.shape[1] if t is not None else 0
+        o = torch.zeros((r, F + n_t), device=dev, dtype=torch.float32)
+        xh = torch.empty((r, F), device=dev, dtype=torch.float32) if j.get("save", True) else None
+        rs = torch.empty((r,), device=dev, dtype=torch.float32) if j.get("save", True) else None
+        heads = j.get("heads", [])
+        ys = [torch.empty((r, H), device=dev, dtype=torch.float32) for _ in heads]
+        res.append(dict(out=o, xhat=xh, rstd=rs, ys=ys))
+        part.append(j.get("part")); z.append(j.get("z")); bias.append(j.get("bias"))
+        gamma.append(j["gamma"]); beta.append(j["beta"]); out.append(o); ldo.append(F + n_t)
+        xhat.append(xh); rstd.append(rs); tail.append(t); tld.append(t.stride(0) if t is not None else 0); tn.append(n_t)
+        rows.append(r); nh.append(len(heads))
+        for h in range(2):
+            w.append(heads[h][0] if h < len(heads) else None)
+            b.append(heads[h][1] if h < len(heads) else None)
+            y.append(ys[h] if h < len(heads) else None)
+    check(lib.drq_ln_l1_fwd(len(jobs), _ptr_array(part) if splitk else None, _ptr_array(z) if not splitk else None,
+                            _ptr_array(bias), _ptr_array(gamma), _ptr_array(beta), _ptr_array(out), _int_array(ldo),
+                            _ptr_array(xhat), _ptr_array(rstd), _ptr_array(tail), _int_array(tld), _int_array(tn),
+                            _int_array(rows), _int_array(nh), _ptr_array(w), _ptr_array(b), _ptr_array(y), F, H, splitk,
+                            slab, _stream()), "drq_ln_l1_fwd")
+    return res
+
+
+def policy_out_l1_fwd(p2, w3, b3, srow0, F, std, clip, noise_hi, ha_hi, noise_lo=None, ha_lo=None, heads=None):
+    """policy output layer + sample (+ first layers on the hi rows).  ha_hi [rows-srow0][F+A] holds h in its first F
+    columns; returns dict(p3, mu_hi, mu_lo, ys)."""
+    lib = _lib.load()
+    rows, H = p2.shape
+    A = w3.shape[0]
+    dev = p2.device
+    p3 = torch.empty((rows, A), device=dev, dtype=torch.float32)
+    mu_hi = torch.empty((rows - srow0, A), device=dev, dtype=torch.float32)
+    mu_lo = torch.empty((srow0, A), device=dev, dtype=torch.float32) if noise_lo is not None else None
+    ys = [torch.empty((rows - srow0, H), device=dev, dtype=torch.float32) for _ in (heads or [])]
+    check(lib.drq_policy_out_l1_fwd(ptr(p2), ptr(w3), ptr(b3), ptr(p3), rows, srow0, H, A, F, float(std),
+                                    float(clip if clip is not None else 0.0), int(clip is not None), ptr(noise_hi),
+                                    ptr(mu_hi), ptr(ha_hi), ha_hi.stride(0), ptr(noise_lo), ptr(mu_lo), ptr(ha_lo),
+                                    (ha_lo.stride(0) if ha_lo is not None else 0), len(heads or []),
+                                    _ptr_array([h[0] for h in heads]) if heads else None,
+                                    _ptr_array([h[1] for h in heads]) if heads else None,
+                                    _ptr_array(ys) if heads else None, _stream()), "drq_policy_out_l1_fwd")
+    return dict(p3=p3, mu_hi=mu_hi, mu_lo=mu_lo, ys=ys)

@@ -71,7 +71,10 @@ int drq_conv3x3_fwd_wino(const float* x, const float* w, const float* bias, floa
                          long y_bs, long y_cs, long y_rs, long y_off, drq_stream_t stream);
 int drq_conv3x3_dgrad_wino(const float* dy_pad, const float* w, const float* mask, float* dx, int nb, int hout,
                            long dx_bs, long dx_cs, long dx_rs, long dx_off, drq_stream_t stream);
-/* ... and their weight / bias gradient in the same form (same contract as drq_conv3x3_wgrad for cin = 32, stride 1). */
+/* ... and their weight / bias gradient in the same form: the contract of drq_conv3x3_wgrad for cin = 32, stride 1, with
+ * ONE more precondition: dy must be the interior of a ZERO-PADDED buffer (the kernel reads row and column `hout` of
+ * every plane as the empty half of the last 2x2 tile), i.e. dy_rs >= hout+1, dy_cs >= (hout+1)*dy_rs and zeros there --
+ * the update's [nb][32][hout+4][hout+4] gradient buffers (pad 2) satisfy it.  A contiguous dy returns DRQ_EARG. */
 int drq_conv3x3_wgrad_wino(const float* x, const float* dy, float* dw, float* db, int nb, int hin, long dy_bs,
                            long dy_cs, long dy_rs, long dy_off, float* ws, size_t ws_bytes, drq_stream_t stream);
 /* dw [32][cin][3][3], db [32]; dy addressed as dy[dy_off + b*dy_bs + co*dy_cs + oy*dy_rs + ox]. */
@@ -143,6 +146,29 @@ int drq_mlp_wgrad_dgrad(int nbatch, const float* const* dy, long lddy, const flo
                         float* const* dw, float* const* db, const float* const* w, long ldw, float* const* dx,
                         long lddx, const float* const* mask, int ldmask, int Brows, int Nout, int Kin,
                         drq_stream_t stream);
+
+/* ---- row-local stages fused with the first MLP layer that consumes them (csrc/rowblock.hip), fp32.
+ * drq_ln_l1_fwd: njobs (<= 4) problems  h_j = tanh(LayerNorm(z_j)) (drqv2.py:74-75,100-101; eps 1e-5, F <= 256), with
+ * z_j given either as z[j] [rows_j][F] (splitk == 0) or as the split-K records of drq_gemm_batched_partial (splitk > 0:
+ * element (s, row, f) of problem j at part[j][(s*slab) + row*F + f], plus bias[j][f]); out[j] [rows_j][ldo_j] receives
+ * h_j in columns [0,F) and, if tail[j] is given, tail[j] [rows_j][tail_ld_j] in columns [F, F+tail_n_j) (the critic's
+ * [h, action] input, drqv2.py:117); xhat[j] / rstd[j] (optional) as drq_ln_tanh_fwd writes them -- all bit-identical
+ * to drq_ln_tanh_fwd.  nheads[j] in {0,1,2}: y[2j+h] [rows_j][H] = relu(out_j[:, :F+tail_n_j] w[2j+h]^T + b[2j+h]),
+ * w [H][F+tail_n_j] (16-byte aligned), the first layers of the policy / Q MLPs (drqv2.py:77,103,108); F+tail_n <= 128.
+ * drq_policy_out_l1_fwd: p3 [rows][A] = p2 [rows][H] w3[A][H]^T + b3 (drqv2.py:81; H % 256 == 0, A <= 32); rows >=
+ * srow0 ("hi", the next_obs rows): mu = tanh(p3), a' = clampST(mu + clamp(noise_hi*std, +-clip)) (utils.py:117-126)
+ * written to columns [F, F+A) of ha_hi [rows-srow0][lda_hi] (mu_hi optional), and with nheads == 2
+ * y[h] [rows-srow0][H] = relu([ha_hi[:, :F], a'] w[h]^T + b[h]); rows < srow0 ("lo"): the same sample with noise_lo into
+ * ha_lo / mu_lo when noise_lo is given. */
+int drq_ln_l1_fwd(int njobs, const float* const* part, const float* const* z, const float* const* bias,
+                  const float* const* gamma, const float* const* beta, float* const* out, const int* ldo,
+                  float* const* xhat, float* const* rstd, const float* const* tail, const int* tail_ld,
+                  const int* tail_n, const int* rows, const int* nheads, const float* const* w, const float* const* b,
+                  float* const* y, int F, int H, int splitk, long slab, drq_stream_t stream);
+int drq_policy_out_l1_fwd(const float* p2, const float* w3, const float* b3, float* p3, int rows, int srow0, int H, int A,
+                          int F, float std, float clip, int use_clip, const float* noise_hi, float* mu_hi, float* ha_hi,
+                          long lda_hi, const float* noise_lo, float* mu_lo, float* ha_lo, long lda_lo, int nheads,
+                          const float* const* w, const float* const* b, float* const* y, drq_stream_t stream);
 
 /* ---- output layer of the Q heads, nn.Linear(hidden, 1) (drqv2.py:106,111), nz (<= 8) problems per launch:
  * q = h w^T + b;  backward: dh = (dq w) * (h > 0), and if dw/db are given dw = dq^T h, db = sum dq. */
@@ -260,11 +286,22 @@ typedef struct {
                               * the augmentation) multiplies on the bf16 MFMA too; storage, the augmentation arithmetic,
                               * conv1's weight gradient, LayerNorm, the output heads, losses, Adam and
                               * Polyak stay fp32.  act() always runs in fp32. */
-  void* const* timing_events; /* optional (may be NULL): host array of 4 hipEvent_t created with timing enabled.
-                              * Instrumentation for bench.py's roofline: [0],[1] are recorded on `stream` right
-                              * before / after the conv2 forward launch of phase 3, [2],[3] around the conv3 dgrad
-                              * launch of phase 5 (both are conv3x3_kernel<32,41,1>). */
+  void* const* timing_events; /* optional (may be NULL): host array of timing_n hipEvent_t created with timing enabled.
+                              * Instrumentation for bench.py's roofline: pairs recorded on `stream` right before / after
+                              * [0],[1] the conv2 forward launch of phase 3; [2],[3] the conv3 input-gradient launch of
+                              * phase 5; [4],[5] the launch(es) of the conv2..4 weight gradients; [6],[7] phase 4 (the
+                              * heads of the critic update: trunks .. trunk input gradient); [8],[9] phases 6-7 without
+                              * the critic's optimiser step (the heads of the actor update).  Pairs beyond timing_n
+                              * are not recorded. */
+  int timing_n;              /* entries of timing_events (0, 4, 6, 8 or 10) */
+  int flags;                 /* schedule switches for A/B measurements and for tests that hold both forms to the oracle:
+                              * DRQ_STEP_NO_ROW_FUSION (1): LayerNorm / policy output layer / first MLP layers as separate
+                              * launches (the round-2 schedule) instead of csrc/rowblock.hip's fused ones;
+                              * DRQ_STEP_NO_GEMM3 (2): hidden-layer gradients on the round-2 kernels instead of
+                              * csrc/gemm3.hip.  0 = the production schedule. */
 } DrqStep;
+#define DRQ_STEP_NO_ROW_FUSION 1
+#define DRQ_STEP_NO_GEMM3 2
 
 /* Parameter arena: tensors in parameters() order of encoder, critic, actor, critic_target, each start
  * aligned to 64 floats, each network's segment padded to a multiple of 512 floats (a segment is one optimiser

@@ -165,6 +165,21 @@ def test_conv_wgrad_winograd(ops, hin, nb):
     assert nerr(dw, dw_d.double().cpu()) <= 3e-6 and nerr(db, db_d.double().cpu()) <= 3e-6
 
 
+def test_conv_wgrad_winograd_refuses_a_contiguous_dy(ops):
+    """The Winograd weight-gradient kernel reads one row / column past every dy plane as zeros: dy must be the interior
+    of a zero-padded buffer (include/drqv2_hip.h).  A contiguous dy would give wrong sums silently: DRQ_EARG instead."""
+    from drqv2_amd._lib import DrqError
+    x = torch.relu(rnd(2, 32, 39, 39, seed=1)).cuda()
+    dy = rnd(2, 32, 37, 37, seed=2).cuda()
+    with pytest.raises(DrqError):
+        ops.conv3x3_wgrad(x, dy, 1, wino=True)
+    pad = torch.zeros(2, 32, 41, 41).cuda()
+    pad[:, :, 2:-2, 2:-2] = dy
+    dw, db = ops.conv3x3_wgrad(x, pad[:, :, 2:-2, 2:-2], 1, wino=True)
+    ref = torch.nn.grad.conv2d_weight(x.double().cpu(), (32, 32, 3, 3), dy.double().cpu())
+    assert nerr(dw, ref) <= 3e-6
+
+
 @pytest.mark.parametrize("cin,hin,stride,nb", [(9, 84, 2, 3), (32, 41, 1, 5), (32, 39, 1, 2), (32, 37, 1, 7)])
 def test_conv_wgrad(ops, cin, hin, stride, nb):
     hout = (hin - 3) // stride + 1

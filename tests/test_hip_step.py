@@ -691,3 +691,24 @@ def test_two_rank_rccl_update_equals_full_batch(exchange):
     """The same equivalence with one GPU per rank and the gradient exchanges over RCCL (backend nccl): the path
     bench.py --gpus N takes.  Runs wherever the box shows two or more GPUs."""
     _run_two_ranks("nccl", exchange)
+
+
+@pytest.mark.parametrize("B", [256, 37])
+def test_production_store_setting_equals_the_test_setting(B):
+    """Every parity test above asks conv1_aug_kernel to keep BOTH views' encoder input (store_aug_next=True) so that it
+    can look at them; production keeps the obs view only (n_store = B).  The two settings must be the same update: bit
+    for bit the same parameters, gradients and Adam moments after two updates, and the same metrics."""
+    cfg = dict(C=9, A=6, F=50, H=1024, B=B, lr=1e-4, sched="linear(1.0,0.1,500000)", wseed=0, bseed=7, updates=2,
+               step0=0, smooth=True)
+    outs = []
+    for store in (True, False):
+        ag = make_agent(cfg)
+        ag._engine.store_aug_next = store
+        ms = [run_hip(ag, cfg, u)[0] for u in range(cfg["updates"])]
+        torch.cuda.synchronize()
+        eng = ag._engine
+        outs.append((ms, eng.params.clone(), eng.grads.clone(), eng.adam_m.clone(), eng.adam_v.clone()))
+    (m0, *a0), (m1, *a1) = outs
+    assert m0 == m1
+    for x, y in zip(a0, a1):
+        assert torch.equal(x, y)
