@@ -16,11 +16,15 @@ replay batches.  Contract: python bench.py --gpus N --steps K --warmup W  ->  ON
               hidden under compute.  The same line carries `weak` (256 samples PER GPU, value
               = global samples/s / 256) and `n1_same_workload` (rank 0 alone on the plain single-GPU path, same
               job, same box).  --workload / --task / --batch / --weak override.
-  roofline  = dominant kernel conv3x3_wino_kernel<41> (conv2 forward on both views + conv3 dgrad, Winograd F(2x2,3x3)
-              on the f32 MFMA), timed live with events on the launch stream.  `achieved` counts the matrix FLOPs the
-              kernel EXECUTES (256 v_mfma_f32_16x16x4_f32 per 16 output tiles), so `frac` is a true fraction of the MFMA
-              peak; `direct_equiv_tflops` is the direct-form work (2*32*288 per output pixel) over the same
-              time, which Winograd's 2.25x saving can push past the peak.
+  roofline  = fp32: dominant kernel conv3x3_wino_kernel<41> (conv2 forward on both views + conv3 dgrad, Winograd
+              F(2x2,3x3) on the f32 MFMA), timed live with events on the launch stream.  `achieved` counts the matrix FLOPs
+              the kernel EXECUTES (256 v_mfma_f32_16x16x4_f32 per 16 output tiles): `frac` == `frac_executed` is a true
+              fraction of the MFMA peak; `frac_direct_form` prices the same launches at SURVEY 8(d)'s direct-form FLOPs
+              (2*32*288 per output pixel), which Winograd's 2.25x saving can push past 1; `frac_whole_step` is
+              F_alg * updates/s / peak.  `other_kernels` carries the two weakest parts of the update, timed the same way.
+              bf16 (configs[4]): the update is HBM-bound on its fp32 activations: `bound` "hbm", algorithmic bytes of
+              SURVEY 8(d) per update over the measured update time against 8 TB/s.
+              `traffic` is replayed from a committed --pmc measurement of the same command (`traffic_replayed`: true).
   cpu_baseline = the CPU oracle (oracle/drq_oracle.py, kind "port") on the host cores, rank 0, N=1 only.
 """
 import argparse
@@ -65,7 +69,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=256, help="global batch (strong) or per-GPU batch (--weak)")
     ap.add_argument("--weak", action="store_true", help="N>1: `value` is the weak-scaling run (--batch per GPU)")
     ap.add_argument("--strong", action="store_true", help="N>1: split ONE --batch over the GPUs (the default)")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "allreduce", "direct"],
+    ap.add_argument("--exchange", default="auto", choices=["auto", "allreduce", "direct", "zero1"],
                     help="gradient exchange of the data-parallel path (drqv2_amd.engine.GradExchange)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="rehearsal only: gloo carries the CUDA tensors through the host, so that several ranks can "
@@ -303,10 +307,11 @@ def main():
                    "backend": ("rccl" if args.backend == "nccl" else "gloo (rehearsal)") if use_dp else None,
                    "baseline_config": {"config2": 1, "config4": 3}[workload] if args.task is None else None},
         "alg_gflop_per_update": alg_flops_per_update(B_global, A, F, H) / 1e9,
-        "frac_fp32_peak_whole_step": alg_flops_per_update(B_global, A, F, H) * args.steps / dt /
-                                     (PEAK_FP32_TFLOPS * 1e12 * world),
         "last_metrics": res["last_metrics"],
     }
+    frac_whole = alg_flops_per_update(B_global, A, F, H) * args.steps / dt / (PEAK_FP32_TFLOPS * 1e12 * world)
+    if args.dtype == "f32":
+        out["frac_fp32_peak_whole_step"] = frac_whole
     if use_dp and main_run.agent._engine.exchange is not None:
         ex = main_run.agent._engine.exchange
         out["exchange"] = {"mode": ex.mode, "choice_by_bucket_floats": {str(k): v for k, v in ex.choice.items()},
@@ -314,10 +319,18 @@ def main():
 
     if not args.no_roofline and args.dtype == "f32":
         # every rank runs it (the updates inside carry the data-parallel collectives); rank 0 reports
-        roof = roofline_conv(main_run.agent, B_local, main_run.it, main_run.step)
+        roof = roofline_conv(main_run.agent, B_local, main_run.it, main_run.step, A, F)
+        roof["frac_whole_step"] = frac_whole
         main_run.agent.flush()
         if rank == 0:
             out["roofline"] = roof
+    elif not args.no_roofline:
+        if rank == 0:
+            out["roofline"] = roofline_hbm(main_run.agent, task, B_local, A, res["ms_per_step"], args.dtype)
+    if use_dp and world > 1 and not args.no_extras:
+        exposed = exposed_exchange_us(main_run)
+        if rank == 0 and exposed is not None:
+            out.setdefault("exchange", {})["exposed_us_per_update"] = exposed
     main_run.close()
 
     extras = not (args.no_extras or args.host_batch or args.device_replay or args.dp_schedule or args.dtype != "f32")
@@ -349,7 +362,7 @@ def main():
                                        "steps": k2, "warmup": w2}
             r.close()
         dist.barrier()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.dtype == "f32":
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(task, B_local)
     if rank == 0:
         print(json.dumps(out), file=json_out, flush=True)
@@ -361,11 +374,11 @@ def main():
     return 0
 
 
-def conv_traffic():
+def kernel_traffic(name="kernel_traffic.json"):
     """Memory-side KB per launch of the kernels of the bench, as measured by tools/pmc_bench.sh (separate rocprofv3
-    --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over `python bench.py`) and written, with the commit it was measured at, to
-    profiles/kernel_traffic.json.  None when that file is missing."""
-    path = os.path.join(ROOT, "profiles", "kernel_traffic.json")
+    --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over `python bench.py ...`) and written, with the commit it was measured at,
+    to profiles/<name>.  None when that file is missing."""
+    path = os.path.join(ROOT, "profiles", name)
     try:
         with open(path) as f:
             return json.load(f)
@@ -373,42 +386,44 @@ def conv_traffic():
         return None
 
 
-def roofline_conv(agent, B, it, step):
+def roofline_conv(agent, B, it, step, A, F):
     """conv3x3_wino_kernel<41,...>: its two launches per update (conv2 forward on 2B frames, conv3 dgrad on B), timed
     IN the update with HIP events the library records around those two launches on the stream they run on
     (DrqStep.timing_events).  In isolation, back to back, the same launches run ~10 % slower (the chip holds a
     lower clock under an MFMA-only load than inside the update's mix of kernels), and rocprofv3's per-kernel
-    average of the bench agrees with the in-update figure, not with the isolated one."""
+    average of the bench agrees with the in-update figure, not with the isolated one.  The same events bracket the
+    Winograd weight-gradient launch and the two head sections (`other_kernels`)."""
     import torch
     eng = agent._engine
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(10)]
     for e in ev:
         e.record()                     # torch creates the hipEvent_t at the first record
     torch.cuda.synchronize()
     eng.set_timing_events(ev)
-    t_f, t_d, n = 0.0, 0.0, 0
+    acc = [0.0] * 5
+    n = 0
     try:
         for u in range(24):
             agent.update(it, step)
             step += 2
             torch.cuda.synchronize()   # the events of THIS update have been reached before they are re-recorded
             if u >= 4:
-                t_f += ev[0].elapsed_time(ev[1]) * 1e-3
-                t_d += ev[2].elapsed_time(ev[3]) * 1e-3
+                for k in range(5):
+                    acc[k] += ev[2 * k].elapsed_time(ev[2 * k + 1]) * 1e-3
                 n += 1
     finally:
         eng.set_timing_events(None)
-    t_f /= n
-    t_d /= n
-    traffic, note = None, None
-    tr = conv_traffic()
+    t_f, t_d, t_w, t_hc, t_ha = (a / n for a in acc)
+    traffic, note, tcommit = None, None, None
+    tr = kernel_traffic()
     names = ("conv3x3_wino_kernel<41, false, true, 0>", "conv3x3_wino_kernel<41, true, false, 0>")   # fwd 2B, dgrad B
     if tr is not None and B == tr.get("B") and all(n in tr.get("kernels", {}) for n in names):
         per = [(2 * tr["kernels"][n]["FETCH_SIZE_KB"] + tr["kernels"][n]["WRITE_SIZE_KB"]) * 1024 for n in names]
         traffic = sum(per) / len(per)
+        tcommit = tr.get("commit")
         note = (f"bytes per launch, mean of the two launches, (2*FETCH_SIZE+WRITE_SIZE)*1024 from separate --pmc passes of "
-                f"the bench at B={tr['B']} (profiles/kernel_traffic.json, measured at commit {tr.get('commit')}); "
-                "algorithmic bytes are 210 MB (fwd: 110 in + 100 out) / 155 MB (dgrad: 55 in + 50 mask + 50 out)")
+                f"the bench at B={tr['B']} (profiles/kernel_traffic.json, measured at commit {tcommit}); NOT measured in "
+                "this run; algorithmic bytes are 210 MB (fwd: 110 in + 100 out) / 155 MB (dgrad: 55 in + 50 mask + 50 out)")
     # executed matrix work: a unit = 16 output tiles (2x2 pixels each) x 32 channels x 16 positions x 8 k-steps
     # = 256 v_mfma_f32_16x16x4_f32 of 2*16*16*4 FLOP; 20x20 tiles cover the 39x39 outputs of a frame
     units_f, units_d = (2 * B * 400 + 15) // 16, (B * 400 + 15) // 16
@@ -416,18 +431,99 @@ def roofline_conv(agent, B, it, step):
     fl_f = 2 * 32 * 288 * (2 * B) * 39 * 39          # the direct form's FLOPs for the same outputs
     fl_d = 2 * 32 * 288 * B * 39 * 39
     ach = (ex_f + ex_d) / (t_f + t_d) / 1e12
+    direct = (fl_f + fl_d) / (t_f + t_d) / 1e12
+    # the Winograd weight gradient of conv2..4 (one launch): per tile 16 positions x 32x32 MACs; tiles 20^2, 19^2, 18^2
+    ex_w = B * (400 + 361 + 324) * 16 * 32 * 32 * 2
+    fl_w = 2 * 32 * 288 * B * (39 * 39 + 37 * 37 + 35 * 35)
+    T = 2 * 39200 * F
+    P = 2 * (F * H + H * H + H * A)
+    Q = 2 * ((F + A) * H + H * H + H)
+    fl_hc, fl_ha = B * (6 * T + 2 * P + 8 * Q), B * (2 * T + 2 * P + 4 * Q)
+    other = {
+        "conv3x3_wgrad_wino3_kernel": {
+            "what": "weight gradients of conv2..4 in one launch (Winograd, 256 accumulators per wave)", "us": 1e6 * t_w,
+            "executed_tflops": ex_w / t_w / 1e12, "frac_executed": ex_w / t_w / 1e12 / PEAK_FP32_TFLOPS,
+            "frac_direct_form": fl_w / t_w / 1e12 / PEAK_FP32_TFLOPS},
+        "heads_critic_update": {
+            "what": "phase 4: four trunks, policy, twin-Q forward, TD loss, backward to the encoder output "
+                    "(6T + 2P + 8Q of SURVEY 8d)", "us": 1e6 * t_hc, "alg_gflop": fl_hc / 1e9,
+            "tflops": fl_hc / t_hc / 1e12, "frac": fl_hc / t_hc / 1e12 / PEAK_FP32_TFLOPS},
+        "heads_actor_update": {
+            "what": "phases 6-7 without the critic's optimiser step: critic trunk + twin-Q forward, actor loss, backward "
+                    "to the policy and the actor trunk (2T + 2P + 4Q)", "us": 1e6 * t_ha, "alg_gflop": fl_ha / 1e9,
+            "tflops": fl_ha / t_ha / 1e12, "frac": fl_ha / t_ha / 1e12 / PEAK_FP32_TFLOPS},
+    }
     return {"kernel": "conv3x3_wino_kernel<41> (Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32)", "bound": "mfma",
             "achieved": ach, "peak": PEAK_FP32_TFLOPS,
-            "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "traffic": traffic, "traffic_note": note,
+            "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "frac_executed": ach / PEAK_FP32_TFLOPS,
+            "frac_direct_form": direct / PEAK_FP32_TFLOPS, "direct_form_tflops": direct,
+            "traffic": traffic, "traffic_replayed": traffic is not None, "traffic_measured_at_commit": tcommit,
+            "traffic_note": note,
             "achieved_counts": "matrix FLOPs the kernel executes (Winograd needs 16/36 of the direct form's, on 20x20 "
                                "tiles of 2x2 for 39x39 outputs); the VALU transforms (56 adds per tile and channel) "
                                "share the f32 datapath with the MFMA and are not counted",
-            "direct_equiv_tflops": (fl_f + fl_d) / (t_f + t_d) / 1e12,
-            "frac_direct_equiv": (fl_f + fl_d) / (t_f + t_d) / 1e12 / PEAK_FP32_TFLOPS,
             "avg_launch_us": 0.5e6 * (t_f + t_d), "launch_us": {"conv2_fwd_2B": 1e6 * t_f, "conv3_dgrad_B": 1e6 * t_d},
             "executed_gflop_per_launch": {"conv2_fwd_2B": ex_f / 1e9, "conv3_dgrad_B": ex_d / 1e9},
             "alg_gflop_per_launch": {"conv2_fwd_2B": fl_f / 1e9, "conv3_dgrad_B": fl_d / 1e9}, "frames_per_launch": B,
-            "timing": "hipEvent pairs recorded by the library around the two launches inside 20 update() calls"}
+            "other_kernels": other,
+            "timing": "hipEvent pairs recorded by the library around the launches inside 20 update() calls"}
+
+
+PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable with a float4 copy)
+
+
+def alg_hbm_bytes_per_update(agent, B, A):
+    """inputs + saved activations of the obs branch written once and read once (fp32) + Adam 28 B/param +
+    Polyak 12 B/critic param."""
+    n_all = sum(p.numel() for m in (agent.encoder, agent.actor, agent.critic) for p in m.parameters())
+    n_critic = sum(p.numel() for p in agent.critic.parameters())
+    inputs = B * (2 * 9 * 84 * 84 + 4 * A + 8)
+    acts = 2 * B * 4 * 32 * (41 * 41 + 39 * 39 + 37 * 37 + 35 * 35)
+    return inputs + acts + 28 * n_all + 12 * n_critic
+
+
+def roofline_hbm(agent, task, B, A, ms_per_step, dtype):
+    """bf16 (BASELINE configs[4]): with the matrix work on the bf16 MFMA the update is bound by the HBM traffic of its
+    fp32 activations (balance ~312 FLOP/B against ~240 FLOP/B of the path).  Whole-update figure: algorithmic
+    bytes per update over the measured update time; `traffic` = memory-side bytes per update summed over every kernel of
+    a committed --pmc measurement of this command, when there is one for this workload."""
+    alg = alg_hbm_bytes_per_update(agent, B, A)
+    ach = alg / (ms_per_step * 1e-3) / 1e9
+    traffic, note, tcommit = None, None, None
+    tr = kernel_traffic(f"kernel_traffic_{dtype}_{task}_b{B}.json")
+    if tr is not None and tr.get("B") == B:
+        traffic = sum((2 * k["FETCH_SIZE_KB"] + k["WRITE_SIZE_KB"]) * 1024 * k.get("launches_per_update", 1.0)
+                      for k in tr["kernels"].values() if k["FETCH_SIZE_KB"] == k["FETCH_SIZE_KB"])
+        tcommit = tr.get("commit")
+        note = (f"bytes per update: sum over all kernels of launches x (2*FETCH_SIZE+WRITE_SIZE)*1024, separate --pmc passes "
+                f"of this command (profiles/kernel_traffic_{dtype}_{task}_b{B}.json, commit {tcommit}); NOT measured in this run")
+    return {"kernel": "whole update (HBM-bound on the fp32 activations with the matrix work on the bf16 MFMA)",
+            "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
+            "alg_mbytes_per_update": alg / 1e6, "ms_per_update": ms_per_step,
+            "traffic": traffic, "traffic_replayed": traffic is not None, "traffic_measured_at_commit": tcommit,
+            "traffic_note": note,
+            "achieved_counts": "SURVEY 8(d) algorithmic HBM bytes per update (inputs, obs-branch activations written once and "
+                               "read once in fp32, Adam 28 B/param, Polyak 12 B/param) / measured time per update"}
+
+
+def exposed_exchange_us(runner, updates=12):
+    """Data parallel: how long the compute stream WAITS for each gradient exchange, per update (events around the stream
+    waits; a separate short pass, the events themselves cost the stream a bubble each).  None without a process group."""
+    eng = runner.agent._engine
+    if eng.pg is None:
+        return None
+    eng.profile_exchange = True
+    eng.exchange_wait_us = {}
+    try:
+        for _ in range(updates):
+            runner.agent.update(runner.it, runner.step)
+            runner.step += 2
+        runner.agent.flush()
+        runner.torch.cuda.synchronize()
+        res = eng.collect_exchange_waits()
+    finally:
+        eng.profile_exchange = False
+    return res
 
 
 def cpu_baseline(task, B):
@@ -446,15 +542,18 @@ def cpu_baseline(task, B):
     ag = O.OracleAgent(enc, actor, critic, lr, stddev_schedule=sched)
     batch = synth.make_batch(B, A, 9, seed=0, smooth=True)
     draws = synth.make_draws(B, A, seed=0)
+    # bounded sample (~10-30 s of CPU work): fewer timed updates at the large-batch configurations
+    warm, timed = (2, 4) if B <= 512 else (1, 2)
     ts = []
-    for u in range(6):
+    for u in range(warm + timed):
         t0 = time.perf_counter()
         ag.update(batch, 2 * u, *draws)
         ts.append(time.perf_counter() - t0)
-    ts = sorted(ts[2:])
-    med = 0.5 * (ts[1] + ts[2])
+    ts = sorted(ts[warm:])
+    med = 0.5 * (ts[(timed - 1) // 2] + ts[timed // 2])
     return {"value": 1.0 / med, "unit": "updates/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/drq_oracle.py OracleAgent.update, {task} B={B} fp32, 2 warm-up + 4 timed updates, median"}
+            "sample": f"oracle/drq_oracle.py OracleAgent.update, {task} B={B} fp32, {warm} warm-up + {timed} timed updates, "
+                      "median"}
 
 
 if __name__ == "__main__":

@@ -183,7 +183,8 @@ class DrQV2Agent:
         on its contiguous slice; otherwise the iterator already yields this rank's shard.
         global_metrics: the returned metrics are means over the GLOBAL batch (one more 32-byte all-reduce per
         update); by default they are the means over this rank's shard (the gradients are always global).
-        exchange: "allreduce" | "direct" | "auto" -- drqv2_amd.engine.GradExchange."""
+        exchange: "allreduce" | "direct" | "zero1" | "auto" -- drqv2_amd.engine.GradExchange ("zero1": Adam sharded over the
+        ranks, each steps 1/world of every segment and the stepped parameters are all-gathered)."""
         self._engine.enable_data_parallel(process_group, global_metrics, exchange)
         self._batch_is_global = batch_is_global
 
@@ -251,6 +252,55 @@ class DrQV2Agent:
             metrics["actor_ent"] = A * (0.5 + 0.5 * math.log(2 * math.pi) + math.log(stddev))
         return metrics
 
+    # ---- the update in the reference's pieces (drqv2.py:177-228, :241-246) -----------------------------------------
+    def encode(self, obs, next_obs, step):
+        """aug + encoder of both views as update() does (drqv2.py:241-246), for callers that issue update_critic /
+        update_actor themselves: obs / next_obs uint8 [B,C,84,84]; returns the features (obs, next_obs) [B, 39200], views
+        of the step workspace.  Consumes the two shift draws of the reference.  The encoder's backward inside
+        update_critic uses the activations THIS call saved (the autograd graph of the reference's `self.encoder(obs)`)."""
+        obs, next_obs = (torch.as_tensor(t, device=self.device).contiguous() for t in (obs, next_obs))
+        n = obs.shape[0]
+        sh_o, sh_n = self.aug.draw(n, self.device), self.aug.draw(n, self.device)      # RNG draws 1, 2
+        stddev = utils.schedule(self.stddev_schedule, step)
+        return self._engine.begin_manual(obs, next_obs, sh_o.reshape(n, 2).contiguous(), sh_n.reshape(n, 2).contiguous(),
+                                         stddev, self.stddev_clip, self.critic_target_tau)
+
+    def update_critic(self, obs, action, reward, discount, next_obs, step):
+        """drqv2.py:177-204.  obs / next_obs: the features encode() returned for this batch.  Issues the critic loss, its
+        backward through the encoder, critic_opt.step() and encoder_opt.step(); consumes the reference's third draw
+        (utils.py:119).  `step` must be the step encode() was called with (the stddev schedule is evaluated there)."""
+        metrics = dict()
+        f32 = lambda t: torch.as_tensor(t, device=self.device).to(torch.float32).contiguous()
+        n = obs.shape[0]
+        n_c = _standard_normal((n, self._engine.A), dtype=torch.float32, device=self.device)   # draw 3 (:183)
+        sums = self._engine.manual_critic(obs, f32(action), f32(reward).view(-1), f32(discount).view(-1), next_obs, n_c)
+        if self.use_tb:
+            s = sums.tolist()
+            inv = 1.0 / n
+            metrics["critic_target_q"] = s[1] * inv
+            metrics["critic_q1"] = s[2] * inv
+            metrics["critic_q2"] = s[3] * inv
+            metrics["critic_loss"] = s[4] * inv
+        return metrics
+
+    def update_actor(self, obs, step):
+        """drqv2.py:206-228, after update_critic of the same batch.  Consumes the reference's fourth draw."""
+        metrics = dict()
+        m = getattr(self._engine, "_manual", None)
+        if m is None:
+            raise _lib.DrqError("update_actor(): call update_critic() for this batch first")
+        n, A = m["B"], self._engine.A
+        n_a = _standard_normal((n, A), dtype=torch.float32, device=self.device)               # draw 4 (:211)
+        stddev = utils.schedule(self.stddev_schedule, step)
+        sums = self._engine.manual_actor(n_a)
+        if self.use_tb:
+            s = sums.tolist()
+            inv = 1.0 / n
+            metrics["actor_loss"] = s[5] * inv
+            metrics["actor_logprob"] = s[6] * inv
+            metrics["actor_ent"] = A * (0.5 + 0.5 * math.log(2 * math.pi) + math.log(stddev))
+        return metrics
+
     # ---- snapshots: train.py:192-204 pickles the whole agent --------------------------------
     def flush(self):
         """Data parallel only: finish the Adam(actor) step the last update() left overlapped with its gradient
@@ -267,6 +317,7 @@ class DrQV2Agent:
         reference agent takes it with `agent.encoder.load_state_dict(s["encoder"])` ...
         `agent.encoder_opt.load_state_dict(s["encoder_opt"])`."""
         self._engine.flush()
+        self._engine.gather_optimizer_state()
         cpu = lambda sd: {k: v.detach().cpu().clone() for k, v in sd.items()}
         out = {"format": "drqv2-reference-state-v1",
                "encoder": cpu(self.encoder.state_dict()), "actor": cpu(self.actor.state_dict()),
@@ -319,6 +370,7 @@ class DrQV2Agent:
 
     def __getstate__(self):
         self._engine.flush()
+        self._engine.gather_optimizer_state()       # sharded optimiser: every rank's snapshot holds complete moments
         cpu = lambda sd: {k: v.detach().cpu().clone() for k, v in sd.items()}
         return {"init": self._init_kwargs, "training": self.training,
                 "encoder": cpu(self.encoder.state_dict()), "actor": cpu(self.actor.state_dict()),

@@ -78,6 +78,8 @@ PROTOTYPES = {
     "drq_actor_dmu": (I, [P, P, L, I, P, P, I, I, P]),
     "drq_adam_flat": (I, [P, P, P, P, L, D, L, F, P, D, P]),
     "drq_ema_flat": (I, [P, P, L, D, P]),
+    "drq_sum_slices": (I, [P, L, I, P, L, P]),
+    "drq_adam_reduce_flat": (I, [P, P, L, I, P, P, L, D, L, F, P]),
     "drq_fill": (I, [P, L, F, P]),
     "drq_u8_normalize": (I, [P, P, L, P]),
     "drq_nstep_gather": (I, [P, P, P, P, P, I, I, L, I, F, P, P, P, P, P, P]),

@@ -610,6 +610,38 @@ __global__ void adam2_kernel(AdamSeg2 a) {
   }
 }
 
+// Data parallel, sharded optimiser (ZeRO-1): this rank owns n parameters of a segment; recv holds the `world` ranks'
+// copies of its gradient slice (recv[r*stride + i], the result of an all-to-all) -- summed here in RANK ORDER (the same
+// order on every rank and in drq_sum_slices: bit-identical to the replicated path) and fed straight into the Adam
+// arithmetic of adam_kernel; the gradient sum never goes back to memory.
+__global__ void adam_reduce_kernel(float* __restrict__ p, const float* __restrict__ recv, long stride, int world,
+                                   float* __restrict__ m, float* __restrict__ v, long n, float neg_step_size,
+                                   float sqrt_bc2, float gscale) {
+#pragma clang fp contract(off)
+  const float w1 = (float)(1.0 - 0.9), b2 = 0.999f, w2 = (float)(1.0 - 0.999), eps = 1e-8f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float gi = recv[i];
+    for (int r = 1; r < world; ++r) gi = __fadd_rn(gi, recv[(long)r * stride + i]);
+    if (gscale != 1.0f) gi *= gscale;
+    const float mi = __fmaf_rn(w1, __fsub_rn(gi, m[i]), m[i]);
+    const float vi = __fmaf_rn(__fmul_rn(gi, w2), gi, __fmul_rn(v[i], b2));
+    const float denom = __fadd_rn(__fdiv_rn(sqrtf(vi), sqrt_bc2), eps);
+    p[i] = __fadd_rn(p[i], __fdiv_rn(__fmul_rn(neg_step_size, mi), denom));
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
+// out[i] = ((in[i] + in[stride + i]) + in[2*stride + i]) + ... : the `world` copies of a gradient slice in rank order
+__global__ void sum_slices_kernel(const float* __restrict__ in, long stride, int world, float* __restrict__ out, long n) {
+#pragma clang fp contract(off)
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float s = in[i];
+    for (int r = 1; r < world; ++r) s = __fadd_rn(s, in[(long)r * stride + i]);
+    out[i] = s;
+  }
+}
+
 __global__ void ema_kernel(const float* __restrict__ p, float* __restrict__ t, long n, float tau,
                            float one_minus_tau) {
 #pragma clang fp contract(off)
@@ -1440,6 +1472,24 @@ DRQ_API int drq_adam_flat(float* p, const float* g, float* m, float* v, long n, 
   const float sqrt_bc2 = (float)sqrt(bc2);
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, g, m, v, n, neg_step_size, sqrt_bc2,
                      gscale, tgt, (float)tau, (float)(1.0 - tau));
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
+DRQ_API int drq_adam_reduce_flat(float* p, const float* recv, long stride, int world, float* m, float* v, long n, double lr,
+                                 long step, float gscale, hipStream_t st) {
+  if (!p || !recv || !m || !v || n <= 0 || step <= 0 || world < 1 || stride < n) return DRQ_EARG;
+  const double bc1 = 1.0 - pow(0.9, (double)step);
+  const double bc2 = 1.0 - pow(0.999, (double)step);
+  hipLaunchKernelGGL(adam_reduce_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, recv, stride, world, m, v, n,
+                     (float)(-(lr / bc1)), (float)sqrt(bc2), gscale);
+  DRQ_LAUNCH_CHECK();
+  return DRQ_OK;
+}
+
+DRQ_API int drq_sum_slices(const float* in, long stride, int world, float* out, long n, hipStream_t st) {
+  if (!in || !out || n <= 0 || world < 1 || stride < n) return DRQ_EARG;
+  hipLaunchKernelGGL(sum_slices_kernel, dim3(grid_for(n)), dim3(256), 0, st, in, stride, world, out, n);
   DRQ_LAUNCH_CHECK();
   return DRQ_OK;
 }

@@ -705,7 +705,8 @@ int publish_sums(const float* sums, float* sums_host, unsigned seq, hipStream_t 
 // and the end of the update reads the target), then the actor loss through the UPDATED critic (:210-216).
 // encoder_opt.step() (:202) is phase 8: the actor update works on obs.detach() encoded BEFORE that step
 // (:255), so nothing in phases 6/7 reads the encoder weights and the step commutes to the end of the update.
-int phase_actor_forward(const Ctx& c) {
+// with_opt = false: the forward only (the critic's optimiser step was issued on its own: phase 10)
+int phase_actor_forward(const Ctx& c, bool with_opt = true) {
   const DrqStep* s = c.s;
   const ParamLayout& P = c.P;
   const int B = s->B, A = s->A, F = s->F, FA = F + A;
@@ -713,6 +714,7 @@ int phase_actor_forward(const Ctx& c) {
   float* feat_obs = c.ws(W_FEAT);
   const HeadOff& cr = P.critic;
 
+  if (with_opt)
   CK(drq_adam_flat(c.p(P.seg[2]), c.g(P.seg[2]), s->adam_m + P.seg[2], s->adam_v + P.seg[2], P.seg[3] - P.seg[2],
                    s->lr, s->step_critic, s->gscale, c.p(P.seg[6]), s->tau, st));
   bool q_l1_done = false;
@@ -887,7 +889,7 @@ DRQ_API int drq_update_phase(const DrqStep* s, int phase) {
       !s->noise_critic || !s->noise_actor || !s->base_grid || !s->grads || !s->adam_m || !s->adam_v || !s->sums)
     return DRQ_EARG;
   Ctx c{s, param_layout(s->C, s->A, s->F, s->H), ws_layout(s->B, s->C, s->A, s->F, s->H), (hipStream_t)s->stream};
-  if (phase < -1 || phase > 9) return DRQ_EARG;
+  if (phase < -1 || phase > 13) return DRQ_EARG;
   c.fuse_actor_loss = phase == -1 || phase == 1;
   if (phase == 3 || phase == 0 || phase == -1) CK(phase_encode(c));
   if (phase == 4 || phase == 0 || phase == -1) {
@@ -909,6 +911,22 @@ DRQ_API int drq_update_phase(const DrqStep* s, int phase) {
   }
   if (phase == 8) CK(phase_encoder_opt(c));
   if (phase == 9) CK(phase_actor_opt(c));
+  // the reference's method boundaries (DrQV2Agent.update_critic / update_actor, drqv2.py:177-228) cut phase 6 apart:
+  if (phase == 10) {                        // critic_opt.step() alone (:201), no Polyak
+    const ParamLayout& P = c.P;
+    CK(drq_adam_flat(c.p(P.seg[2]), c.g(P.seg[2]), s->adam_m + P.seg[2], s->adam_v + P.seg[2], P.seg[3] - P.seg[2], s->lr,
+                     s->step_critic, s->gscale, nullptr, 0.0, c.st));
+  }
+  if (phase == 11) CK(phase_actor_forward(c, false));   // actor loss through the (already stepped) critic (:210-216)
+  if (phase == 12) {                        // utils.soft_update_params(critic, critic_target, tau) (:259-260)
+    const ParamLayout& P = c.P;
+    CK(drq_ema_flat(c.p(P.seg[2]), c.p(P.seg[6]), P.seg[3] - P.seg[2], s->tau, c.st));
+  }
+  if (phase == 13) {                        // the actor update's own draw (:210-211) from the stored policy output
+    const int F = s->F, A = s->A, FA = F + A;
+    CK(drq_trunc_normal_sample(c.ws(W_P3), s->noise_actor, s->std, s->clip, 1, c.ws(W_MU_O), c.ws(W_HA_C2) + F, FA, s->B,
+                               A, c.st));
+  }
   return 0;
 }
 

@@ -99,16 +99,26 @@ class GradExchange:
                (world-1)/world of it through each hop); rank r adds them in rank order (the same order on every
                rank: bit-identical results everywhere); an all-gather returns the reduced slices.  Needs the
                bucket length to divide by world*64 floats (segments are padded to 512 floats: world 2, 4, 8).
-    auto       times both on scratch copies of the real buckets at enable time (max over ranks) and keeps the faster
-               per bucket -- which one wins depends on the bucket size and the RCCL build, and this repository's
-               CI box has one GPU, so the choice is made where the job runs, by measurement."""
+    zero1      sharded optimiser step (ZeRO-1) on the same two-phase pattern: all-to-all of the GRADIENT slices, then
+               rank r adds its `world` copies in rank order and steps Adam on the slice of the segment it owns in ONE
+               kernel (drq_adam_reduce_flat: the summed gradient never returns to memory), then an all-gather of the
+               stepped PARAMETER slices.  Same bytes on the links as `direct`, 1/world of the optimiser's HBM traffic
+               per rank, and the optimiser step leaves the compute stream.  Adam moments are maintained only for the
+               owned slice (StepEngine.gather_optimizer_state() reassembles them for snapshots).  Bit-identical to
+               `direct` + replicated Adam.
+    auto       times the candidates on scratch copies of the real buckets at enable time (max over ranks): exchange +
+               replicated Adam for `allreduce` and `direct`, the whole sharded sequence for `zero1`, and keeps the
+               fastest per bucket -- which one wins depends on the bucket size and the RCCL build, and this
+               repository's CI box has one GPU, so the choice is made where the job runs, by measurement."""
 
-    MODES = ("allreduce", "direct", "auto")
+    MODES = ("allreduce", "direct", "auto", "zero1")
 
     def __init__(self, pg, world, device, mode="allreduce"):
         if mode not in self.MODES:
             raise ValueError(f"exchange mode {mode!r}: one of {self.MODES}")
         self.pg, self.world, self.device = pg, world, torch.device(device)
+        import torch.distributed as dist
+        self.rank = dist.get_rank(pg) if world > 1 or dist.is_initialized() else 0
         self.mode = mode
         self.choice = {}          # bucket length -> "allreduce" | "direct"  (auto)
         self.timings_us = {}      # bucket length -> {"allreduce": us, "direct": us}
@@ -132,14 +142,66 @@ class GradExchange:
         n = t.numel()
         recv, red = self._bufs(n)
         dist.all_to_all_single(recv, t, group=self.pg)                    # recv[j] = rank j's copy of MY slice
-        torch.sum(recv.view(self.world, n // self.world), dim=0, out=red)  # fixed (rank) order
+        self._sum_slices(recv, red, n // self.world)                      # fixed (rank) order
         dist.all_gather_into_tensor(t, red, group=self.pg)
+
+    def _sum_slices(self, recv, red, ns):
+        if recv.is_cuda:
+            with torch.cuda.device(self.device):
+                check(_lib.load().drq_sum_slices(ptr(recv), ns, self.world, ptr(red), ns,
+                                                 torch.cuda.current_stream(self.device).cuda_stream), "drq_sum_slices")
+        else:       # gloo rehearsals on CPU tensors (tests): the same rank-order sum
+            acc = recv[:ns].clone()
+            for r in range(1, self.world):
+                acc += recv[r * ns:(r + 1) * ns]
+            red.copy_(acc)
+
+    def _zero1(self, g, p, m, v, lr, step, gscale, step_fn):
+        """Runs on the current stream: gradient slices in, Adam on the owned slice, parameter slices out."""
+        import torch.distributed as dist
+        n = g.numel()
+        ns = n // self.world
+        recv, red = self._bufs(n)
+        dist.all_to_all_single(recv, g, group=self.pg)
+        lo = self.rank * ns
+        ps, ms, vs = p[lo:lo + ns], m[lo:lo + ns], v[lo:lo + ns]
+        if step_fn is not None:                     # CPU tests hand in the oracle's Adam
+            step_fn(ps, recv.view(self.world, ns), ms, vs)
+        else:
+            with torch.cuda.device(self.device):
+                check(_lib.load().drq_adam_reduce_flat(ptr(ps), ptr(recv), ns, self.world, ptr(ms), ptr(vs), ns,
+                                                       float(lr), int(step), float(gscale),
+                                                       torch.cuda.current_stream(self.device).cuda_stream),
+                      "drq_adam_reduce_flat")
+        red.copy_(ps)
+        dist.all_gather_into_tensor(p, red, group=self.pg)
+
+    def start_zero1(self, g, p, m, v, lr, step, gscale=1.0, step_fn=None):
+        """Sharded optimiser step of one segment (g, p, m, v: the segment's views of the four arenas) once the work
+        queued so far on the current stream has produced g; returns a handle whose wait() orders the current stream
+        after the stepped parameters have arrived from every rank."""
+        if not self.direct_ok(g.numel()):
+            raise _lib.DrqError(f"zero1: a segment of {g.numel()} floats does not split over {self.world} ranks")
+        if self.device.type != "cuda":
+            self._zero1(g, p, m, v, lr, step, gscale, step_fn)
+            return _Done()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        side = self._side
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            self._zero1(g, p, m, v, lr, step, gscale, step_fn)
+        return _StreamWork(side, (g, p))
+
+    def sharded(self, n):
+        """Does the bucket of n floats take the sharded optimiser step?"""
+        return self._pick(n) == "zero1"
 
     def _pick(self, n):
         if self.mode == "allreduce" or not self.direct_ok(n):
             return "allreduce"
-        if self.mode == "direct":
-            return "direct"
+        if self.mode in ("direct", "zero1"):
+            return self.mode
         return self.choice.get(n, "allreduce")
 
     def start(self, t):
@@ -160,28 +222,38 @@ class GradExchange:
         return _StreamWork(side, t)
 
     def calibrate(self, lengths, iters=20, warmup=5):
-        """auto: time both strategies for each bucket length on scratch tensors; all ranks agree on the result
-        (MAX over ranks of the per-exchange time)."""
+        """auto: time the candidates for each bucket length on scratch tensors; all ranks agree on the result (MAX over
+        ranks of the per-update time).  allreduce / direct: the exchange plus the replicated Adam step it needs
+        afterwards; zero1: the whole sharded sequence."""
         import time
         import torch.distributed as dist
+        cuda = self.device.type == "cuda"
         for n in sorted(set(lengths)):
             if not self.direct_ok(n):
                 self.choice[n] = "allreduce"
                 continue
-            t = torch.zeros(n, device=self.device, dtype=torch.float32)
+            t, pp, mm, vv = (torch.zeros(n, device=self.device, dtype=torch.float32) for _ in range(4))
             res = {}
-            for name in ("allreduce", "direct"):
-                fn = (lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)) if name == "allreduce" \
-                    else (lambda: self._direct(t))
+
+            def adam_full():
+                if cuda:
+                    from . import ops
+                    ops.adam_flat(pp, t, mm, vv, 1e-4, 1)
+
+            cands = {"allreduce": lambda: (dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg), adam_full()),
+                     "direct": lambda: (self._direct(t), adam_full())}
+            if cuda:
+                cands["zero1"] = lambda: self._zero1(t, pp, mm, vv, 1e-4, 1, 1.0, None)
+            for name, fn in cands.items():
                 for _ in range(warmup):
                     fn()
-                if self.device.type == "cuda":
+                if cuda:
                     torch.cuda.synchronize(self.device)
                 dist.barrier(group=self.pg)
                 t0 = time.perf_counter()
                 for _ in range(iters):
                     fn()
-                if self.device.type == "cuda":
+                if cuda:
                     torch.cuda.synchronize(self.device)
                 dt = torch.tensor([(time.perf_counter() - t0) / iters * 1e6], device=self.device, dtype=torch.float64)
                 dist.all_reduce(dt, op=dist.ReduceOp.MAX, group=self.pg)
@@ -244,6 +316,10 @@ class StepEngine:
         self._timing_array = None # ctypes array of hipEvent_t (set_timing_events)
         self._timing_n = 0
         self.step_flags = 0       # DrqStep.flags: 1 = no row fusion, 2 = no gemm3 (A/B measurements, both-form tests)
+        self.metrics_spin = 256         # read_sums(): polls of the host mirror before the waiting thread starts to sleep
+        self.profile_exchange = False   # bench.py: event pairs around every wait for a gradient exchange
+        self.exchange_wait_us = {}      # bucket name -> [us the compute stream waited], see collect_exchange_waits()
+        self._wait_events = []
         self._side = None         # side stream of the metric-sums exchange
         self._side_busy = False
         self.bf16 = False             # DrqStep.bf16: the update's convs / GEMMs on the bf16 MFMA (set_compute_dtype)
@@ -315,6 +391,22 @@ class StepEngine:
             except RuntimeError as err:          # a backend without all-to-all: every bucket takes the all-reduce
                 self.exchange.choice = {}
                 self.exchange.timings_us = {"error": str(err)[:200]}
+
+    def gather_optimizer_state(self):
+        """Sharded optimiser (zero1): every rank keeps the Adam moments of its own slice of a segment only; before a
+        snapshot the slices are exchanged so that adam_m / adam_v are complete everywhere.  No-op otherwise."""
+        if self.exchange is None or self.world <= 1:
+            return
+        import torch.distributed as dist
+        self.flush()
+        for b, e in grad_buckets_overlap(self.layout):
+            n = e - b
+            if not self.exchange.sharded(n):
+                continue
+            ns = n // self.world
+            for arena in (self.adam_m, self.adam_v):
+                mine = arena[b + self.rank * ns: b + (self.rank + 1) * ns].clone()
+                dist.all_gather_into_tensor(arena[b:e], mine, group=self.pg)
 
     def _allreduce_async(self, t):
         """SUM over the ranks that starts once the work queued so far has produced `t` and runs beside what is
@@ -401,16 +493,37 @@ class StepEngine:
         with torch.cuda.device(self.device):
             check(_lib.load().drq_update_phase(ctypes.byref(desc), k), f"drq_update_phase({k})")
 
+    def _wait(self, work, name):
+        """work.wait() (the current stream waits for the exchange); with profile_exchange the wait is bracketed by two
+        events on the compute stream: their distance is the time the exchange was NOT hidden under compute."""
+        if not self.profile_exchange or self.device.type != "cuda":
+            work.wait()
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        work.wait()
+        e1.record()
+        self._wait_events.append((name, e0, e1))
+
+    def collect_exchange_waits(self):
+        """After a synchronize: mean exposed microseconds per update and bucket since profile_exchange was switched on."""
+        acc = {}
+        for name, e0, e1 in self._wait_events:
+            acc.setdefault(name, []).append(e0.elapsed_time(e1) * 1e3)
+        self._wait_events = []
+        return {k: {"mean_us": sum(v) / len(v), "max_us": max(v), "samples": len(v)} for k, v in acc.items()}
+
     def flush_encoder(self):
         """Data parallel: the deferred Adam(encoder) of the last update (phase 8).  Before the encoder is read."""
         if self._pending_enc is None:
             return
         work, desc, keep = self._pending_enc
         self._pending_enc = None
-        work.wait()
-        if self.device.type == "cuda":
-            desc.stream = self._stream()
-        self._phase(desc, 8)
+        self._wait(work, "encoder_grads")
+        if desc is not None:                                    # replicated step (the sharded one came with the exchange)
+            if self.device.type == "cuda":
+                desc.stream = self._stream()
+            self._phase(desc, 8)
         del keep
 
     def flush(self):
@@ -422,10 +535,11 @@ class StepEngine:
             return
         work, desc, keep = self._pending
         self._pending = None
-        work.wait()
-        if self.device.type == "cuda":
-            desc.stream = self._stream()
-        self._phase(desc, 9)
+        self._wait(work, "actor_grads")
+        if desc is not None:
+            if self.device.type == "cuda":
+                desc.stream = self._stream()
+            self._phase(desc, 9)
         del keep
 
     # ---- the step ------------------------------------------------------------------------
@@ -492,16 +606,24 @@ class StepEngine:
             self._phase(d, 3)                                   # aug + encoder forward: no actor weights yet
             self.flush()                                        # previous update's Adam(actor), reduce done by now
             self._phase(d, 4)                                   # critic loss, backward to the encoder output
-            w_critic = self._allreduce_async(self.grads[c0:c1])  # 16.7 MB, under the encoder backward
+            ex = self.exchange
+            z_critic = ex is not None and ex.sharded(c1 - c0)
+            if z_critic:     # gradient slices -> Adam on the owned slice -> stepped parameters back, beside phase 5
+                w_critic = ex.start_zero1(self.grads[c0:c1], self.params[c0:c1], self.adam_m[c0:c1], self.adam_v[c0:c1],
+                                          d.lr, steps[0])
+            else:
+                w_critic = self._allreduce_async(self.grads[c0:c1])  # 16.7 MB, under the encoder backward
             self._phase(d, 5)
-            w_critic.wait()
+            self._wait(w_critic, "critic_grads")
+            # phase 6 = critic_opt.step() + Polyak + the actor loss; with the sharded step already done: Polyak + loss
+            ph6 = (lambda: (self._phase(d, 12), self._phase(d, 11))) if z_critic else (lambda: self._phase(d, 6))
             if not self.global_metrics:
                 # metrics of THIS rank's shard (means over its rows): published by phase 6 itself, no exchange
                 d.sums_host = ptr(self.sums_host) if mirror else None
-                self._phase(d, 6)                               # Adam(critic), actor loss (sums complete)
+                ph6()                                           # Adam(critic), actor loss (sums complete)
                 self._last_seq = seq if mirror else None
             else:
-                self._phase(d, 6)
+                ph6()
                 # global metric sums: reduced and published beside phase 7 (a side stream, so that the 32-byte
                 # exchange's latency is not inserted between phases 6 and 7)
                 if self.device.type == "cuda":
@@ -520,9 +642,76 @@ class StepEngine:
                     self._last_seq = None
             self._phase(d, 7)                                   # actor backward
             # encoder (0.1 MB) and actor (12.3 MB) gradients: reduced under the next update's encoder forward
-            self._pending_enc = (self._allreduce_async(self.grads[e0:e1]), d, keep)
-            self._pending = (self._allreduce_async(self.grads[a0:a1]), d, keep)
+            def hand_over(b, e, step_no):
+                if ex is not None and ex.sharded(e - b):        # the optimiser step travels with the exchange
+                    return (ex.start_zero1(self.grads[b:e], self.params[b:e], self.adam_m[b:e], self.adam_v[b:e], d.lr,
+                                           step_no), None, keep)
+                return (self._allreduce_async(self.grads[b:e]), d, keep)
+            self._pending_enc = hand_over(e0, e1, steps[1])
+            self._pending = hand_over(a0, a1, steps[2])
         del keep
+        return self.sums
+
+    # ---- the update in the reference's pieces (DrQV2Agent.encode / update_critic / update_actor) -------------------
+    def begin_manual(self, obs, next_obs, shift_obs, shift_next, std, clip, tau):
+        """aug + encoder forward of both views (phase 3) for an update issued piece by piece; returns the feature views
+        (obs, next_obs) of the workspace.  Single GPU only."""
+        if self.pg is not None:
+            raise _lib.DrqError("update_critic / update_actor as separate calls are not available with data parallelism: "
+                                "use update()")
+        B = obs.shape[0]
+        for nm, t in (("obs", obs), ("next_obs", next_obs)):
+            if t.dtype != torch.uint8 or tuple(t.shape) != (B, self.C, 84, 84) or not t.is_contiguous():
+                raise _lib.DrqError(f"encode(): {nm} must be contiguous uint8 [{B},{self.C},84,84], got {t.dtype} "
+                                    f"{tuple(t.shape)}")
+        if B > self.MAX_BATCH:
+            raise _lib.DrqError(f"encode(): batch of {B} rows; at most {self.MAX_BATCH} per GPU")
+        steps = (self.critic_opt.begin_step(), self.encoder_opt.begin_step(), self.actor_opt.begin_step())
+        d = self.make_desc(B, B, std, clip, tau, steps)
+        d.sums_host = None
+        d.obs, d.next_obs = ptr(obs), ptr(next_obs)
+        d.shift_obs, d.shift_next = ptr(shift_obs), ptr(shift_next)
+        # not known yet and not read by phase 3 (drq_update_phase wants every pointer set)
+        for f in ("action", "reward", "discount", "noise_critic", "noise_actor"):
+            setattr(d, f, ptr(shift_obs))
+        self._manual = {"d": d, "keep": [obs, next_obs, shift_obs, shift_next], "B": B, "stage": "encoded"}
+        self._phase(d, 3)
+        feat = self.ws_view("FEAT", B, (2 * B, 39200))
+        return feat[:B], feat[B:]
+
+    def manual_critic(self, feat_obs, action, reward, discount, feat_next, noise_critic):
+        m = getattr(self, "_manual", None)
+        if m is None or m["stage"] != "encoded":
+            raise _lib.DrqError("update_critic(): call encode() for this batch first (the encoder backward needs the "
+                                "activations that call saved)")
+        d, B = m["d"], m["B"]
+        feat = self.ws_view("FEAT", B, (2 * B, 39200))
+        for dst, src, nm in ((feat[:B], feat_obs, "obs"), (feat[B:], feat_next, "next_obs")):
+            if tuple(src.shape) != (B, 39200) or src.dtype != torch.float32 or src.device != self.device:
+                raise _lib.DrqError(f"update_critic(): {nm} must be the [B, 39200] features encode() returned")
+            if src.data_ptr() != dst.data_ptr():
+                dst.copy_(src)                      # features the caller produced some other way: the heads use them
+        m["keep"] += [action, reward, discount, noise_critic]
+        d.action, d.reward, d.discount = ptr(action), ptr(reward), ptr(discount)
+        d.noise_critic, d.noise_actor = ptr(noise_critic), ptr(noise_critic)   # the actor's draw comes with update_actor
+        d.stream = self._stream()
+        for k in (4, 5, 10, 8):
+            self._phase(d, k)
+        m["stage"] = "critic"
+        return self.sums
+
+    def manual_actor(self, noise_actor):
+        m = getattr(self, "_manual", None)
+        if m is None or m["stage"] != "critic":
+            raise _lib.DrqError("update_actor(): call update_critic() for this batch first")
+        d = m["d"]
+        m["keep"].append(noise_actor)
+        d.noise_actor = ptr(noise_actor)
+        d.stream = self._stream()
+        for k in (13, 11, 7, 9):
+            self._phase(d, k)
+        self._last_seq = None
+        self._manual = None
         return self.sums
 
     def read_sums(self):
@@ -534,13 +723,19 @@ class StepEngine:
             return self.sums.tolist()                      # no host mirror: drain the stream
         want = self._last_seq if self._last_seq < 2 ** 31 else self._last_seq - 2 ** 32
         seq = self._sums_seq
-        t0 = None
+        import time
+        # A short spin (the sums usually land within tens of microseconds of the call when the host runs ahead of the
+        # GPU), then sleeps with a back-off: the host thread shares its core with the simulator in train.py, and the
+        # update's tail (actor backward, Adam, Polyak: ~150 us) still hides a late wake-up.
         spins = 0
-        while int(seq) != want:
+        while int(seq) != want and spins < self.metrics_spin:
             spins += 1
-            if spins % 4096 == 0:
-                import time
-                t0 = t0 or time.monotonic()
+        if int(seq) != want:
+            t0 = time.monotonic()
+            nap = 20e-6
+            while int(seq) != want:
+                time.sleep(nap)
+                nap = min(nap * 1.5, 60e-6)      # a late wake-up must stay inside the update's ~150 us tail
                 if time.monotonic() - t0 > 30.0:
                     torch.cuda.synchronize()               # surfaces a device fault, if that is why nothing arrived
                     if int(seq) != want:

@@ -215,6 +215,14 @@ int drq_actor_dmu(const float* dha1, const float* dha2, long ld, int col0, const
  * utils.soft_update_params (utils.py:42-45) into tgt.  g is multiplied by gscale first (1 = exact). */
 int drq_adam_flat(float* p, const float* g, float* m, float* v, long n, double lr, long step, float gscale,
                   float* tgt, double tau, drq_stream_t stream);
+/* ---- data-parallel exchanges on a fully connected xGMI node (new): the `world` ranks' copies of this rank's
+ * slice of a gradient bucket, as an all-to-all delivers them (copy r at in[r*stride + i]), are added in RANK ORDER (the
+ * same order everywhere: every rank ends with bit-identical sums).  drq_sum_slices writes the sum; drq_adam_reduce_flat
+ * (ZeRO-1: sharded optimiser state) feeds it straight into torch.optim.Adam's arithmetic (drq_adam_flat's, bit for bit)
+ * for the n parameters this rank owns -- the summed gradient never returns to memory. */
+int drq_sum_slices(const float* in, long stride, int world, float* out, long n, drq_stream_t stream);
+int drq_adam_reduce_flat(float* p, const float* recv, long stride, int world, float* m, float* v, long n, double lr,
+                         long step, float gscale, drq_stream_t stream);
 int drq_ema_flat(const float* p, float* t, long n, double tau, drq_stream_t stream);
 int drq_fill(float* p, long n, float v, drq_stream_t stream);
 /* obs/255-0.5 on raw uint8 frames (drqv2.py:64 as reached from act(), drqv2.py:165-166); y = tanh(x) */
@@ -334,6 +342,11 @@ enum {
  *   8  Adam(encoder) (:202)   commutes to here: phases 6/7 work on features encoded before it (:255)
  *   9  Adam(actor) (:221)
  * Composite ids kept for callers that exchange at coarser points: 0 = 3,4,5; 1 = 6,7; 2 = 8,9.
+ * For hosts that follow the reference's METHOD boundaries (DrQV2Agent.update_critic / update_actor, drqv2.py:177-228)
+ * phase 6 is also available in pieces: 10 = Adam(critic) alone (no Polyak), 11 = the actor loss of phase 6 without the
+ * optimiser step, 12 = Polyak alone (utils.soft_update_params), 13 = re-draw the actor update's action from the policy
+ * output stored by phase 4 with s->noise_actor (update_critic does not know that draw yet).  update_critic = 4, 5, 10, 8;
+ * update_actor = 13, 11, 7, 9; results equal phase -1 bit for bit (tests/test_hip_step.py).
  * A data-parallel host SUM-all-reduces the critic gradients while 5 runs, the encoder gradients while 6/7 run,
  * the metric sums after 6 and the actor gradients after 7; 8 may be deferred until the next update's phase 3
  * and 9 until its phase 4 (or drq_act_forward), so both exchanges overlap compute. */

@@ -230,6 +230,118 @@ def test_direct_exchange_equals_allreduce_world2():
     assert sorted(ret.keys()) == [0, 1] and ret[0] == ret[1]
 
 
+def _zero1_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import drq_oracle as O
+        from drqv2_amd import _lib
+        from drqv2_amd.engine import GradExchange, grad_buckets_overlap
+        lay = _lib.param_layout(9, 3, 20, 64)
+        lr = 1e-3
+        for bi, (b, e) in enumerate(grad_buckets_overlap(lay)):
+            n = e - b
+            gen = lambda seed: torch.Generator().manual_seed(seed)
+            g_local = torch.randn(n, generator=gen(200 + 10 * bi + rank)) * 1e-2
+            p0 = torch.randn(n, generator=gen(7 + bi))                   # same on every rank
+            m0 = torch.randn(n, generator=gen(8 + bi)) * 1e-3
+            v0 = torch.rand(n, generator=gen(9 + bi)) * 1e-4
+            # replicated path: SUM of the gradients (direct exchange: rank-order sum), then Adam on the whole segment
+            ex_d = GradExchange(dist.group.WORLD, world, "cpu", "direct")
+            g_sum = g_local.clone()
+            ex_d.start(g_sum).wait()
+            p_ref, m_ref, v_ref = p0.clone(), m0.clone(), v0.clone()
+            O.adam_step(p_ref, g_sum, m_ref, v_ref, 3, lr)
+            # sharded path: the product's slicing and collectives, the oracle's Adam as the per-slice step
+            ex = GradExchange(dist.group.WORLD, world, "cpu", "zero1")
+            assert ex.sharded(n) and ex._pick(n) == "zero1"
+            p, m, v = p0.clone(), m0.clone(), v0.clone()
+
+            def step_fn(ps, copies, ms, vs):
+                gs = copies[0].clone()
+                for r in range(1, copies.shape[0]):
+                    gs += copies[r]                                          # rank order
+                O.adam_step(ps, gs, ms, vs, 3, lr)
+            ex.start_zero1(g_local.clone(), p, m, v, lr, 3, step_fn=step_fn).wait()
+            assert torch.equal(p, p_ref), (rank, bi)                         # every parameter, on every rank
+            ns = n // world
+            own = slice(rank * ns, (rank + 1) * ns)
+            assert torch.equal(m[own], m_ref[own]) and torch.equal(v[own], v_ref[own])
+            other = slice((1 - rank) * ns, (2 - rank) * ns)
+            assert torch.equal(m[other], m0[other])                          # moments of the other rank's slice: untouched
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_zero1_sharded_adam_equals_replicated_world2():
+    """GradExchange 'zero1' (gradient slices in by all-to-all, rank-order sum + Adam on the owned slice, stepped
+    parameters out by all-gather) on the three buckets of a small layout: parameters bit-identical to the replicated
+    path (direct exchange + Adam on the whole segment) on every rank; each rank maintains the moments of its slice only."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_zero1_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: "ok", 1: "ok"}
+
+
+def test_zero1_schedule_order():
+    """Host logic with the sharded optimiser: the optimiser steps travel with the exchanges (no phase 6 / 8 / 9 on the
+    compute stream: Polyak (12) and the actor loss (11) instead of 6; the deferred hand-overs only wait)."""
+    import types
+    import drqv2
+    from drqv2_amd._lib import DrqStep
+    from drqv2_amd.engine import grad_buckets_overlap
+    ag = drqv2.DrQV2Agent((9, 84, 84), (3,), "cpu", 1e-3, 20, 64, 0.01, 2000, 2, "0.2", 0.3, False)
+    eng = ag._engine
+    log = []
+
+    class Work:
+        def __init__(self, name):
+            self.name = name
+
+        def wait(self):
+            log.append(("wait", self.name))
+
+    class FakeExchange:
+        mode = "zero1"
+
+        def sharded(self, n):
+            return True
+
+        def start_zero1(self, g, p, m, v, lr, step, gscale=1.0, step_fn=None):
+            off = (g.data_ptr() - eng.grads.data_ptr()) // 4
+            assert (p.data_ptr() - eng.params.data_ptr()) // 4 == off and p.numel() == g.numel()
+            assert (m.data_ptr() - eng.adam_m.data_ptr()) // 4 == off and (v.data_ptr() - eng.adam_v.data_ptr()) // 4 == off
+            log.append(("zero1", (off, off + g.numel()), step))
+            return Work((off, off + g.numel()))
+
+    eng.pg, eng.world, eng.rank, eng.exchange = object(), 2, 0, FakeExchange()
+    eng._phase = lambda d, k: log.append(("phase", k, int(d.step_actor)))
+
+    def make_desc(self, B_local, B_global, std, clip, tau, steps):
+        d = DrqStep()
+        d.B, d.global_B = B_local, B_global
+        d.step_critic, d.step_enc, d.step_actor = steps
+        d.lr = 1e-3
+        return d
+    eng.make_desc = types.MethodType(make_desc, eng)
+    batch = synth.make_batch(4, 3)
+    draws = synth.make_draws(8, 3, seed=1)
+    args = list(batch) + [t[:4] for t in draws]
+    crit, enc, act = grad_buckets_overlap(eng.layout)
+    eng.update(*args, 0.2, 0.3, 0.01, B_global=8)
+    assert log == [("phase", 3, 1), ("phase", 4, 1), ("zero1", crit, 1), ("phase", 5, 1), ("wait", crit),
+                   ("phase", 12, 1), ("phase", 11, 1), ("phase", 7, 1), ("zero1", enc, 1), ("zero1", act, 1)]
+    del log[:]
+    eng.update(*args, 0.2, 0.3, 0.01, B_global=8)
+    assert log[:4] == [("wait", enc), ("phase", 3, 2), ("wait", act), ("phase", 4, 2)]     # no phase 8 / 9
+    del log[:]
+    ag.flush()
+    assert log == [("wait", enc), ("wait", act)]
+
+
 def test_shard_bounds():
     from drqv2_amd.engine import shard_bounds
     assert shard_bounds(256, 1, 0, True) == (0, 256, 256)
@@ -248,23 +360,46 @@ def test_bench_self_launch_starts_ranks_without_touching_the_gpu(monkeypatch):
     bench = importlib.import_module("bench")
     started = []
 
+    import io
+
     class FakeProc:
+        """rank 1 fails at once; the others would run on (poll() -> None) until the parent stops them"""
         def __init__(self, cmd, env=None, stdout=None):
             started.append((cmd, env, stdout))
-            self.returncode = 0 if env["RANK"] != "1" else 3
+            self.rank = int(env["RANK"])
+            self.returncode = 3 if self.rank == 1 else None
+            self.stdout = io.BytesIO(b'{"metric": "x"}\n') if self.rank == 0 else None
+            self.terminated = False
 
-        def communicate(self):
-            return (b'{"metric": "x"}\n', None)
-
-        def wait(self):
+        def poll(self):
             return self.returncode
 
+        def terminate(self):
+            self.terminated = True
+            self.returncode = -15
+
+        def kill(self):
+            self.returncode = -9
+
+        def wait(self, timeout=None):
+            return self.returncode
+
+    procs_made = []
+    orig_init = FakeProc.__init__
+
+    def init(self, *a, **k):
+        orig_init(self, *a, **k)
+        procs_made.append(self)
+
+    FakeProc.__init__ = init
     monkeypatch.setattr(bench.subprocess, "Popen", FakeProc)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     args = bench.parse_args(["--gpus", "4", "--steps", "3"])
     rc = bench.launch_ranks(args)
     assert rc == 3 and len(started) == 4
+    # the failing rank took the survivors with it (they would otherwise wait for the collective's timeout)
+    assert [p.terminated for p in procs_made] == [True, False, True, True]
     ports = set()
     for r, (cmd, env, out) in enumerate(started):
         assert cmd[0] == sys.executable and cmd[1].endswith("bench.py") and cmd[2:] == ["--gpus", "4", "--steps", "3"]

@@ -30,6 +30,8 @@ def test_signatures_match_reference(iface):
     import utils
     objs = {"DrQV2Agent.__init__": drqv2.DrQV2Agent.__init__, "DrQV2Agent.act": drqv2.DrQV2Agent.act,
             "DrQV2Agent.update": drqv2.DrQV2Agent.update, "DrQV2Agent.train": drqv2.DrQV2Agent.train,
+            "DrQV2Agent.update_critic": drqv2.DrQV2Agent.update_critic,
+            "DrQV2Agent.update_actor": drqv2.DrQV2Agent.update_actor,
             "RandomShiftsAug.__init__": drqv2.RandomShiftsAug.__init__, "Encoder.__init__": drqv2.Encoder.__init__,
             "Actor.__init__": drqv2.Actor.__init__, "Actor.forward": drqv2.Actor.forward,
             "Critic.__init__": drqv2.Critic.__init__, "Critic.forward": drqv2.Critic.forward,

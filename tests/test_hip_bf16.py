@@ -139,22 +139,9 @@ def test_gemm_bf16_trunk_shapes(ops, F):
     assert not bool(border.any())
 
 
-@pytest.mark.parametrize("name", ["cheetah_b64", "humanoid_b32"])
-def test_bf16_update_against_fp64_oracle(name):
-    """Whole update with set_compute_dtype("bf16") against the fp64 oracle of the reference's fp32 arithmetic, same
-    batch, shifts and noise.  There is no reference behaviour to match here (parity unpinned); the bounds are this
-    implementation's measured distances with a margin: metrics 1e-2 relative; features 2e-2 normwise; gradients by
-    direction and norm -- every weight tensor (>= 1024 elements) cosine >= 0.97 and |g| within 10 % (actor: 0.95, 25 %), each network's whole gradient cosine >= 0.98 (measured 0.993 for the encoder).
-    Element-wise agreement is not the criterion: bf16 rounding of the activations flips a fraction of the ReLU
-    decisions near zero, and the bias gradients are small sums of large cancelling terms."""
-    from tests.test_hip_step import WIDE, make_agent, make_oracle, run_hip
-    cfg = WIDE[name]
-    ag = make_agent(cfg).set_compute_dtype("bf16")
-    ref = make_agent(cfg)                                   # the fp32 HIP path on the same inputs
-    o64 = make_oracle(cfg, torch.float64)
-    m, batch, (sh_o, sh_n, n_c, n_a) = run_hip(ag, cfg, 0)
-    m32, _, _ = run_hip(ref, cfg, 0)
-    m64 = o64.update(batch, cfg["step0"], sh_o, sh_n, n_c, n_a, keep=True)
+def _bf16_update_checks(name, ag, cfg, m, m32, m64, o64):
+    """metrics 1e-2 relative; features 2e-2 normwise; every weight tensor (>= 1024 elements) cosine >= 0.97 and |g| within
+    10 % (actor: 0.95, 25 %); each network's whole gradient cosine >= 0.98 (actor 0.95)."""
     worst = 0.0
     for k in m64:
         e = abs(m[k] - m64[k]) / max(1.0, abs(m64[k]))
@@ -184,7 +171,71 @@ def test_bf16_update_against_fp64_oracle(name):
         assert netcos[nm] >= (0.95 if nm == "actor" else 0.98), (nm, netcos[nm])
     print(f"{name} bf16: worst metric rel err {worst:.2e}, features {ferr:.2e}, min tensor cosine {cmin:.5f}, "
           f"max norm deviation {nmax:.2e}, whole-network cosines {netcos}")
+
+
+@pytest.mark.parametrize("name", ["cheetah_b64", "humanoid_b32"])
+def test_bf16_update_against_fp64_oracle(name):
+    """Whole update with set_compute_dtype("bf16") against the fp64 oracle of the reference's fp32 arithmetic, same
+    batch, shifts and noise.  There is no reference behaviour to match here (parity unpinned); the bounds are this
+    implementation's measured distances with a margin (see _bf16_update_checks).
+    Element-wise agreement is not the criterion: bf16 rounding of the activations flips a fraction of the ReLU
+    decisions near zero, and the bias gradients are small sums of large cancelling terms."""
+    from tests.test_hip_step import WIDE, make_agent, make_oracle, run_hip
+    cfg = WIDE[name]
+    ag = make_agent(cfg).set_compute_dtype("bf16")
+    ref = make_agent(cfg)                                   # the fp32 HIP path on the same inputs
+    o64 = make_oracle(cfg, torch.float64)
+    m, batch, (sh_o, sh_n, n_c, n_a) = run_hip(ag, cfg, 0)
+    m32, _, _ = run_hip(ref, cfg, 0)
+    m64 = o64.update(batch, cfg["step0"], sh_o, sh_n, n_c, n_a, keep=True)
+    _bf16_update_checks(name, ag, cfg, m, m32, m64, o64)
     # the parameters moved and stayed finite; a second bf16 update runs from the updated state
     m2, _, _ = run_hip(ag, cfg, 1)
     assert all(v == v and abs(v) < 1e6 for v in m2.values())
     assert bool(torch.isfinite(ag._engine.params).all())
+
+
+def test_config5_shape_humanoid_batch_2048_fp32_and_bf16():
+    """BASELINE configs[4] at ITS shape: humanoid_run (A=21, feature_dim=100), batch_size=2048, one GPU.
+    (a) the fp32 update at that shape against the pinned oracle, held to the bounds of test_wide_batch_update_matches_oracle
+        (metrics 1e-5, features 2e-6, gradients no worse than 2x the fp32 oracle's own error against fp64; ReLU decisions
+        that differ from the fp64 oracle's counted and inside the fp32 error bound) -- so the shape is oracle-covered;
+    (b) the bf16 update on the same batch, shifts and noise against the same fp64 oracle run WITHOUT injected decisions,
+        bounds of _bf16_update_checks (new functionality: parity unpinned by the reference)."""
+    from tests.test_hip_step import (make_agent, make_oracle, run_hip, check_encoder_inputs_bitwise, check_relu_decisions,
+                                     hip_masks, check_critic_decisions, nerr)
+    cfg = dict(C=9, A=21, F=100, H=1024, B=2048, lr=8e-5, sched="linear(1.0,0.1,2000000)", wseed=11, bseed=110,
+               updates=1, step0=1000, smooth=True)
+    B = cfg["B"]
+    # ---- (a) fp32
+    ag = make_agent(cfg)
+    o32, o64 = make_oracle(cfg, torch.float32), make_oracle(cfg, torch.float64)
+    m, batch, (sh_o, sh_n, n_c, n_a) = run_hip(ag, cfg, 0)
+    xin = check_encoder_inputs_bitwise(ag, cfg, batch, sh_o, sh_n)
+    flips, units = check_relu_decisions(ag, cfg, o64, xin[:B])
+    acts, crit_masks = hip_masks(ag, cfg)
+    critic_before = {k: v.clone() for k, v in o64.critic.items()}
+    kw = dict(enc_in_override=(xin[:B], xin[B:]), keep=True, relu_masks=acts, critic_relu_masks=crit_masks)
+    m32 = o32.update(batch, cfg["step0"], sh_o, sh_n, n_c, n_a, **kw)
+    m64 = o64.update(batch, cfg["step0"], sh_o, sh_n, n_c, n_a, **kw)
+    cflips, cunits = check_critic_decisions(o64, critic_before, crit_masks)
+    print(f"humanoid_b2048 fp32: {flips}/{units} encoder and {cflips}/{cunits} critic ReLU decisions differ from fp64")
+    for k in m64:
+        assert m[k] == pytest.approx(m64[k], rel=1e-5, abs=1e-5), (k, m[k], m32[k], m64[k])
+    feat = ag._engine.ws_view("FEAT", B, (2 * B, 39200))
+    assert nerr(feat[:B], o64.last["feat"]) <= 2e-6
+    for nm, mod, key in (("enc", ag.encoder, "g_enc"), ("critic", ag.critic, "g_critic"), ("actor", ag.actor, "g_actor")):
+        for (pn, p), g64, g32 in zip(mod.named_parameters(), o64.last[key].values(), o32.last[key].values()):
+            e_hip, e_o32 = nerr(p.grad, g64), nerr(g32, g64)
+            assert e_hip <= max(2.0 * e_o32, 2e-5 if nm != "actor" else 2e-3), (nm, pn, e_hip, e_o32)
+    del ag, o32, xin, acts, crit_masks
+    torch.cuda.empty_cache()
+    # ---- (b) bf16, against the fp64 oracle's own (un-injected) update
+    o64b = make_oracle(cfg, torch.float64)
+    m64b = o64b.update(batch, cfg["step0"], sh_o, sh_n, n_c, n_a, keep=True)
+    agb = make_agent(cfg).set_compute_dtype("bf16")
+    mb, _, _ = run_hip(agb, cfg, 0)
+    _bf16_update_checks("humanoid_b2048", agb, cfg, mb, m, m64b, o64b)
+    m2, _, _ = run_hip(agb, cfg, 1)
+    assert all(v == v and abs(v) < 1e6 for v in m2.values())
+    assert bool(torch.isfinite(agb._engine.params).all())

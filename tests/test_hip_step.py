@@ -712,3 +712,48 @@ def test_production_store_setting_equals_the_test_setting(B):
     assert m0 == m1
     for x, y in zip(a0, a1):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("name", ["cheetah_b8", "cartpole_b32"])
+def test_update_critic_update_actor_as_separate_calls_equal_update(name):
+    """The reference's public pieces (drqv2.py:177-228): encode -> update_critic -> update_actor ->
+    utils.soft_update_params, issued by the caller, are the same update as update(): same consumption of the global
+    generator (two shift draws, two noise draws, in that order), bit-identical parameters, target, Adam moments and
+    metrics.  (update() fuses these pieces into one call; the pieces cut phase 6 at the method boundaries.)"""
+    import utils
+    cfg = CASES[name]
+    batches = [synth.make_batch(cfg["B"], cfg["A"], cfg["C"], seed=cfg["bseed"] + u, smooth=cfg["smooth"]) for u in range(2)]
+    outs = []
+    for manual in (False, True):
+        ag = make_agent(cfg)
+        ag._engine.fused_rng = False                 # torch's own four calls in both runs (the pieces draw one by one)
+        torch.manual_seed(123)
+        torch.cuda.manual_seed_all(123)
+        ms = []
+        for u, batch in enumerate(batches):
+            step = cfg["step0"] + 2 * u
+            if not manual:
+                ms.append(ag.update(iter([tuple(x.numpy() for x in batch)]), step))
+                continue
+            obs, action, reward, discount, next_obs = utils.to_torch(tuple(x.numpy() for x in batch), ag.device)
+            m = {"batch_reward": float(reward.float().mean())}
+            f_obs, f_next = ag.encode(obs, next_obs, step)
+            m.update(ag.update_critic(f_obs, action, reward, discount, f_next, step))
+            m.update(ag.update_actor(f_obs.detach(), step))
+            utils.soft_update_params(ag.critic, ag.critic_target, ag.critic_target_tau)
+            ms.append(m)
+        torch.cuda.synchronize()
+        eng = ag._engine
+        outs.append((ms, eng.params.clone(), eng.adam_m.clone(), eng.adam_v.clone(), torch.cuda.get_rng_state()))
+    (m0, p0, am0, av0, r0), (m1, p1, am1, av1, r1) = outs
+    assert torch.equal(r0, r1)                       # the generator moved by the same amount
+    assert torch.equal(p0, p1) and torch.equal(am0, am1) and torch.equal(av0, av1)
+    for a, b in zip(m0, m1):
+        assert set(a) == set(b)
+        for k in a:
+            assert a[k] == pytest.approx(b[k], rel=1e-6, abs=1e-7), k     # batch_reward: two ways of taking a mean
+    # out of order: loud errors, nothing silently skipped
+    from drqv2_amd._lib import DrqError
+    ag = make_agent(cfg)
+    with pytest.raises(DrqError):
+        ag.update_actor(torch.zeros(cfg["B"], 39200, device="cuda"), 0)
