@@ -86,9 +86,11 @@ def parse_args(argv=None):
     ap.add_argument("--host-batch", action="store_true",
                     help="the replay iterator yields pinned HOST tensors (the reference boundary): every update "
                          "pays the H2D copy of its batch.  Reported for DESIGN.md section 6; never the headline value")
-    ap.add_argument("--device-replay", action="store_true",
-                    help="batches come from the device-resident replay (drq_nstep_gather, index draws on the host) "
-                         "instead of one fixed resident batch: the SURVEY 8f rank-2 path, reported in DESIGN.md")
+    ap.add_argument("--device-replay", nargs="?", const="indexed", default=None, choices=["indexed", "copy"],
+                    help="batches come from the device-resident replay (index draws on the host) instead of one fixed "
+                         "resident batch: the SURVEY 8f rank-2 path, reported in DESIGN.md.  indexed (default): the frames "
+                         "stay in the store and the fused aug+conv1 launch gathers them; copy: drq_nstep_gather "
+                         "materialises the batch first (the round-2 form)")
     ap.add_argument("--dp-schedule", action="store_true",
                     help="development: run the data-parallel schedule on a one-rank RCCL group (N=1 only)")
     return ap.parse_args(argv)
@@ -190,7 +192,7 @@ class Runner:
         if device_replay:
             import numpy as np
             from drqv2_amd.replay import DeviceReplay
-            store = DeviceReplay(4096, (9, 84, 84), A, 3, 0.99, dev, seed=rank)
+            store = DeviceReplay(4096, (9, 84, 84), A, 3, 0.99, dev, seed=rank, indexed=device_replay != "copy")
             obs_pool = batch[0].cpu().numpy()
             r = np.random.RandomState(rank)
             for e in range(16):                          # 16 episodes of 200 steps drawn from the synthetic frames

@@ -208,6 +208,7 @@ class DrQV2Agent:
             return metrics
 
         batch = next(replay_iter)
+        frames = getattr(batch, "frames", None)      # drqv2_amd.replay.IndexedBatch: obs / next_obs are indices into it
         obs, action, reward, discount, next_obs = utils.to_torch(batch, self.device)
         eng = self._engine
         A = eng.A
@@ -224,9 +225,14 @@ class DrQV2Agent:
 
         stddev = utils.schedule(self.stddev_schedule, step)
         f32 = lambda t: t.to(torch.float32).contiguous()
-        sums = eng.update(obs_l.contiguous(), f32(action_l), f32(reward_l).view(-1), f32(discount_l).view(-1),
-                          next_l.contiguous(), f32(sh_o), f32(sh_n), f32(n_c), f32(n_a), stddev, self.stddev_clip,
-                          self.critic_target_tau, B_global=n_global)
+        if frames is not None:
+            sums = eng.update(frames, f32(action_l), f32(reward_l).view(-1), f32(discount_l).view(-1), frames, f32(sh_o),
+                              f32(sh_n), f32(n_c), f32(n_a), stddev, self.stddev_clip, self.critic_target_tau,
+                              B_global=n_global, obs_index=obs_l.contiguous(), next_obs_index=next_l.contiguous())
+        else:
+            sums = eng.update(obs_l.contiguous(), f32(action_l), f32(reward_l).view(-1), f32(discount_l).view(-1),
+                              next_l.contiguous(), f32(sh_o), f32(sh_n), f32(n_c), f32(n_a), stddev, self.stddev_clip,
+                              self.critic_target_tau, B_global=n_global)
 
         if self.use_tb and self.metrics_on_device:
             inv = 1.0 / (n_global if (eng.pg is None or eng.global_metrics) else (hi - lo))

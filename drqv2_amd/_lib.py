@@ -32,6 +32,7 @@ class DrqStep(C.Structure):
         ("bf16", C.c_int),
         ("timing_events", C.POINTER(C.c_void_p)),
         ("timing_n", C.c_int),
+        ("obs_index", C.c_void_p), ("next_obs_index", C.c_void_p),
         ("flags", C.c_int),
     ]
 
@@ -45,6 +46,7 @@ PROTOTYPES = {
     "drq_aug_fwd_f32": (I, [P, P, P, P, I, I, I, I, P]),
     "drq_conv1_aug_fwd": (I, [P, P, P, P, P, P, P, P, P, I, I, P]),
     "drq_conv1_aug_fwd_bf16": (I, [P, P, P, P, P, P, P, P, P, I, I, P]),
+    "drq_conv1_aug_fwd_indexed": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, P]),
     "drq_conv3x3_fwd": (I, [P, P, P, P, I, I, I, I, I, L, L, L, L, P]),
     "drq_conv3x3_dgrad": (I, [P, P, P, P, I, I, L, L, L, L, P]),
     "drq_conv3x3_fwd_wino": (I, [P, P, P, P, I, I, I, L, L, L, L, P]),

@@ -46,10 +46,12 @@ constexpr int NTHR = 256;                                 // 4 waves (512 with w
                                                           // of 50 us, but the stage times add up either way: 90 vs 86 us)
 constexpr int NWAVE = NTHR / 64;
 constexpr int MAXU = 64;                                  // units per workgroup (shift table); the grid grows beyond it
-constexpr int LDS_BYTES = (XS_FLOATS + U8_ALLOC + H + 2 * MAXU) * 4;
+constexpr int LDS_BYTES = (XS_FLOATS + U8_ALLOC + H + 3 * MAXU) * 4;   // + base grid, shift table, frame table
 
 struct Conv1AugArgs {
-  const uint8_t* obs[2];     // view 0 = obs, view 1 = next_obs: [n][9][84][84]
+  const uint8_t* obs[2];     // view 0 = obs, view 1 = next_obs: [n][9][84][84] -- or, with fidx, a store of frames
+  const long* fidx[2];       // optional: row b of the view is frame fidx[view][b] of obs[view] (device replay: the batch is
+                             // never materialised, the kernel gathers its source rows straight from the store)
   const float* shift[2];     // [n][2] (x, y)
   const float* base;         // [84]
   const float* w;            // [32][9][3][3]
@@ -103,6 +105,7 @@ __global__ __launch_bounds__(NTHR, 2 * NTHR / 256) void conv1_aug_kernel(Conv1Au
   const uint8_t* u8b = reinterpret_cast<const uint8_t*>(u8w);
   float* bg = smem + XS_FLOATS + U8_ALLOC;                         // [84] base grid
   float* shs = bg + H;                                             // [MAXU][2] shifts (x, y) of this workgroup's units
+  int* fof = reinterpret_cast<int*>(shs + 2 * MAXU);               // [MAXU] frame number of the unit's source in obs[view]
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 31, half = lane >> 5;
@@ -130,6 +133,7 @@ __global__ __launch_bounds__(NTHR, 2 * NTHR / 256) void conv1_aug_kernel(Conv1Au
       const int view = f >= a.n ? 1 : 0, fb = f - view * a.n;
       shs[2 * k + 0] = a.shift[view][2 * fb + 0];
       shs[2 * k + 1] = a.shift[view][2 * fb + 1];
+      fof[k] = a.fidx[view] ? (int)a.fidx[view][fb] : fb;
     }
   }
   // A operand: this lane's weights, step s = c*9 + t -> w[cout = col][cin = 2c + half][t]; cin 9 does not exist
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(NTHR, 2 * NTHR / 256) void conv1_aug_kernel(Conv1Au
 #pragma unroll
   for (int r = 0; r < 16; ++r) breg[r] = a.bias[(r & 3) + 8 * (r >> 2) + 4 * half];
   const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, a.y_bytes, 0x00020000);
-  __syncthreads();                                                 // bg, shs
+  __syncthreads();                                                 // bg, shs, fof
 
   const float sc = (float)(2.0 / (double)S);
   auto cl = [&](int v) { v -= PAD; return v < 0 ? 0 : (v > H - 1 ? H - 1 : v); };
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(NTHR, 2 * NTHR / 256) void conv1_aug_kernel(Conv1Au
   // unit = (frame of the stacked [2n] batch, band of output rows); everything here is wave-uniform and comes from
   // LDS tables: no vector-memory load (and so no vmcnt wait) between the DMA issue and the tiles
   struct Unit {
-    int f, r0, R, i0, nr, sy_lo, nsrc;
+    int f, r0, R, i0, nr, sy_lo, nsrc, fo;
     float shx, shy;
   };
   auto make_unit = [&](int k) {
@@ -191,6 +195,7 @@ __global__ __launch_bounds__(NTHR, 2 * NTHR / 256) void conv1_aug_kernel(Conv1Au
     q.nr = 2 * q.R + 1 + (band == NBAND - 1 ? 1 : 0);
     q.shx = shs[2 * k + 0] * sc;
     q.shy = shs[2 * k + 1] * sc;
+    q.fo = fof[k];
     float fa, fbb;
     coordv(q.i0, q.shy, fa);
     coordv(q.i0 + q.nr - 1, q.shy, fbb);
@@ -203,8 +208,8 @@ __global__ __launch_bounds__(NTHR, 2 * NTHR / 256) void conv1_aug_kernel(Conv1Au
   // dwords of the [channel][row][dword] tile; the per-lane SOURCE address does the row gather.  Rows past the
   // band's last source row re-load that row (harmless).
   auto dma_src = [&](const Unit& q) {
-    const int view = q.f >= a.n ? 1 : 0, fb = q.f - view * a.n;
-    const uint8_t* src = a.obs[view] + (long)fb * C * HW;
+    const int view = q.f >= a.n ? 1 : 0;
+    const uint8_t* src = a.obs[view] + (long)q.fo * C * HW;
     for (int k = wid; k < NDMA; k += NWAVE) {
       int e = k * 64 + lane;
       e = e < U8_DWORDS ? e : U8_DWORDS - 1;
@@ -421,7 +426,8 @@ extern "C" DRQ_API void drq_dev_conv1aug_stamps(void* p) { g_conv1aug_stamps = (
 // bf_mma != 0: the layer's products on the bf16 MFMA (the bf16 update path; internal and drq_conv1_aug_fwd_bf16)
 int drq_conv1_aug_fwd_any(int bf_mma, const uint8_t* obs, const float* shift, const uint8_t* obs1, const float* shift1,
                           const float* base_grid, const float* w, const float* bias, float* xaug, float* y, int n,
-                          int n_store, hipStream_t st, const float* const* wino_w, float* wino_u) {
+                          int n_store, hipStream_t st, const float* const* wino_w, float* wino_u, const long* fidx0,
+                          const long* fidx1) {
   if (!obs || !shift || !obs1 || !shift1 || !base_grid || !w || !bias || !y || n <= 0 || n_store < 0 || n_store > 2 * n)
     return DRQ_EARG;
   if (n_store > 0 && !xaug) return DRQ_EARG;
@@ -430,6 +436,7 @@ int drq_conv1_aug_fwd_any(int bf_mma, const uint8_t* obs, const float* shift, co
   if (yb >= (1ull << 31)) return DRQ_EARG;
   Conv1AugArgs a{};
   a.obs[0] = obs; a.obs[1] = obs1;
+  a.fidx[0] = fidx0; a.fidx[1] = fidx1;
   a.shift[0] = shift; a.shift[1] = shift1;
   a.base = base_grid; a.w = w; a.bias = bias; a.xaug = xaug; a.y = y;
   a.n = n; a.n_store = n_store; a.y_bytes = (unsigned)yb; a.stagger = 1; a.stamps = nullptr;
@@ -502,13 +509,23 @@ extern "C" {
 DRQ_API int drq_conv1_aug_fwd(const uint8_t* obs, const float* shift, const uint8_t* obs1, const float* shift1,
                               const float* base_grid, const float* w, const float* bias, float* xaug, float* y, int n,
                               int n_store, hipStream_t st) {
-  return drq_conv1_aug_fwd_any(0, obs, shift, obs1, shift1, base_grid, w, bias, xaug, y, n, n_store, st, nullptr, nullptr);
+  return drq_conv1_aug_fwd_any(0, obs, shift, obs1, shift1, base_grid, w, bias, xaug, y, n, n_store, st, nullptr, nullptr,
+                               nullptr, nullptr);
+}
+
+DRQ_API int drq_conv1_aug_fwd_indexed(const uint8_t* frames, const long* idx, const float* shift, const uint8_t* frames1,
+                                      const long* idx1, const float* shift1, const float* base_grid, const float* w,
+                                      const float* bias, float* xaug, float* y, int n, int n_store, hipStream_t st) {
+  if (!idx || !idx1) return DRQ_EARG;
+  return drq_conv1_aug_fwd_any(0, frames, shift, frames1, shift1, base_grid, w, bias, xaug, y, n, n_store, st, nullptr,
+                               nullptr, idx, idx1);
 }
 
 DRQ_API int drq_conv1_aug_fwd_bf16(const uint8_t* obs, const float* shift, const uint8_t* obs1, const float* shift1,
                                    const float* base_grid, const float* w, const float* bias, float* xaug, float* y,
                                    int n, int n_store, hipStream_t st) {
-  return drq_conv1_aug_fwd_any(1, obs, shift, obs1, shift1, base_grid, w, bias, xaug, y, n, n_store, st, nullptr, nullptr);
+  return drq_conv1_aug_fwd_any(1, obs, shift, obs1, shift1, base_grid, w, bias, xaug, y, n, n_store, st, nullptr, nullptr,
+                               nullptr, nullptr);
 }
 
 }  // extern "C"

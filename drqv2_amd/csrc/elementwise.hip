@@ -886,7 +886,7 @@ struct NstepArgs {
 
 __global__ void nstep_gather_kernel(NstepArgs a) {
 #pragma clang fp contract(off)
-  const int which = blockIdx.y;
+  const int which = a.obs ? blockIdx.y : 2;         // no output frames: the scalars only (grid.y == 1)
   if (which < 2) {
     const int b = blockIdx.x;
     if (b >= a.B) return;
@@ -1505,13 +1505,17 @@ DRQ_API int drq_ema_flat(const float* p, float* t, long n, double tau, hipStream
 DRQ_API int drq_nstep_gather(const uint8_t* frames, const float* action, const float* reward, const float* discount,
                      const long* pos, int B, int A, long frame_bytes, int nstep, float gamma, uint8_t* obs,
                      float* act_out, float* rew_out, float* disc_out, uint8_t* next_obs, hipStream_t st) {
-  if (!frames || !action || !reward || !discount || !pos || !obs || !act_out || !rew_out || !disc_out || !next_obs)
-    return DRQ_EARG;
+  if (!action || !reward || !discount || !pos || !act_out || !rew_out || !disc_out) return DRQ_EARG;
+  if ((obs != nullptr) != (next_obs != nullptr)) return DRQ_EARG;
+  if (obs && !frames) return DRQ_EARG;
   if (B <= 0 || A <= 0 || nstep <= 0 || frame_bytes <= 0 || frame_bytes % 16) return DRQ_EARG;
   if (((uintptr_t)frames | (uintptr_t)obs | (uintptr_t)next_obs) & 15) return DRQ_EARG;
   NstepArgs a{frames, action, reward, discount, pos, obs, next_obs, act_out, rew_out, disc_out, frame_bytes, B, A, nstep,
               gamma};
-  hipLaunchKernelGGL(nstep_gather_kernel, dim3(B, 3), dim3(256), 0, st, a);
+  // obs == next_obs == NULL: action rows and n-step reward / discount only (the frames stay in the store and the
+  // update reads them through DrqStep.obs_index / next_obs_index)
+  if (obs) hipLaunchKernelGGL(nstep_gather_kernel, dim3(B, 3), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(nstep_gather_kernel, dim3((B + 255) / 256, 1), dim3(256), 0, st, a);
   DRQ_LAUNCH_CHECK();
   return DRQ_OK;
 }

@@ -51,7 +51,8 @@ int drq_gemm_batched_partial_any(int bf16, int nbatch, const float* const* A, lo
 // conv1aug.hip (internal): bf_mma selects the bf16-MFMA form of the layer's products
 int drq_conv1_aug_fwd_any(int bf_mma, const uint8_t* obs, const float* shift, const uint8_t* obs1, const float* shift1,
                           const float* base_grid, const float* w, const float* bias, float* xaug, float* y, int n,
-                          int n_store, hipStream_t st, const float* const* wino_w, float* wino_u);
+                          int n_store, hipStream_t st, const float* const* wino_w, float* wino_u, const long* fidx0,
+                          const long* fidx1);
 // conv_wino.hip (internal): the Winograd kernels with the layer's U image prepared by conv1_aug_kernel's rider
 int drq_conv3x3_fwd_wino_pre(const float* x, const float* w, const float* u_image, const float* bias, float* y, int nb,
                              int hin, int relu, long y_bs, long y_cs, long y_rs, long y_off, hipStream_t st);
@@ -455,7 +456,8 @@ int phase_encode(const Ctx& c) {
   const float* wino_w[3] = {c.p(c.P.enc_w[1]), c.p(c.P.enc_w[2]), c.p(c.P.enc_w[3])};
   CK(drq_conv1_aug_fwd_any(c.bf16(), s->obs, s->shift_obs, s->next_obs, s->shift_next, s->base_grid,
                            c.p(c.P.enc_w[0]), c.p(c.P.enc_b[0]), aug, c.ws(W_ACT1), B, s->store_aug_next ? 2 * B : B, st,
-                           c.bf16() ? nullptr : wino_w, c.bf16() ? nullptr : c.ws(W_WINO_U)));
+                           c.bf16() ? nullptr : wino_w, c.bf16() ? nullptr : c.ws(W_WINO_U), s->obs_index,
+                           s->next_obs_index));
   // layers 2..4 on both views in one pass (:244-246)
   CK(encoder_forward(c, nullptr, 2 * B, c.ws(W_ACT1), c.ws(W_ACT2), c.ws(W_ACT3), c.ws(W_FEAT), true));
   return 0;
@@ -853,6 +855,7 @@ int check_step(const DrqStep* s) {
     return DRQ_EARG;
   if (s->C != 9) return DRQ_EARG;   // conv1 kernel is instantiated for frame_stack=3 (cfgs/config.yaml:7)
   if (!s->params || !s->ws) return DRQ_EARG;
+  if ((s->obs_index != nullptr) != (s->next_obs_index != nullptr)) return DRQ_EARG;
   if (s->ws_bytes < drq_step_ws_bytes(s->B, s->C, s->A, s->F, s->H)) return DRQ_EWS;
   return 0;
 }

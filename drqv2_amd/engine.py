@@ -569,10 +569,20 @@ class StepEngine:
         return d
 
     def update(self, obs, action, reward, discount, next_obs, shift_obs, shift_next, noise_critic, noise_actor, std,
-               clip, tau, B_global=None):
-        """All tensors are this rank's shard, on the GPU.  Returns the 8-float sums tensor (device)."""
-        B = obs.shape[0]
-        for nm, t in (("obs", obs), ("next_obs", next_obs)):
+               clip, tau, B_global=None, obs_index=None, next_obs_index=None):
+        """All tensors are this rank's shard, on the GPU.  Returns the 8-float sums tensor (device).
+        obs_index / next_obs_index (int64 [B], device): the batch is not materialised -- obs / next_obs are frame stores
+        ([slots, C*84*84] or [slots, C, 84, 84] uint8) and row b is frame index[b] (DrqStep.obs_index)."""
+        indexed = obs_index is not None
+        if indexed:
+            B = obs_index.numel()
+            for nm, t, ix in (("obs", obs, obs_index), ("next_obs", next_obs, next_obs_index)):
+                if (t.dtype != torch.uint8 or not t.is_contiguous() or t.numel() % (self.C * 84 * 84) or
+                        ix is None or ix.dtype != torch.int64 or ix.numel() != B or not ix.is_contiguous()):
+                    raise _lib.DrqError(f"update(): indexed {nm}: a contiguous uint8 frame store and {B} int64 indices")
+        else:
+            B = obs.shape[0]
+        for nm, t in ((("obs", obs), ("next_obs", next_obs)) if not indexed else ()):
             if t.dtype != torch.uint8 or tuple(t.shape) != (B, self.C, 84, 84) or not t.is_contiguous():
                 raise _lib.DrqError(f"update(): {nm} must be contiguous uint8 [{B},{self.C},84,84] "
                                     f"(replay_buffer.py:185-189), got {t.dtype} {tuple(t.shape)}")
@@ -583,8 +593,10 @@ class StepEngine:
         B_global = B * self.world if B_global is None else B_global
         steps = (self.critic_opt.begin_step(), self.encoder_opt.begin_step(), self.actor_opt.begin_step())
         d = self.make_desc(B, B_global, std, clip, tau, steps)
-        keep = (obs, action, reward, discount, next_obs, shift_obs, shift_next, noise_critic, noise_actor)
+        keep = (obs, action, reward, discount, next_obs, shift_obs, shift_next, noise_critic, noise_actor, obs_index,
+                next_obs_index)
         d.obs, d.next_obs = ptr(obs), ptr(next_obs)
+        d.obs_index, d.next_obs_index = ptr(obs_index), ptr(next_obs_index)
         d.action, d.reward, d.discount = ptr(action), ptr(reward), ptr(discount)
         d.shift_obs, d.shift_next = ptr(shift_obs), ptr(shift_next)
         d.noise_critic, d.noise_actor = ptr(noise_critic), ptr(noise_actor)

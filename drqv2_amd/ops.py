@@ -72,6 +72,21 @@ def conv1_aug_fwd(obs, shift, obs1, shift1, w, b, n_store=None, base=None, bf16=
     return y, xaug
 
 
+def conv1_aug_fwd_indexed(frames, idx, shift, frames1, idx1, shift1, w, b, n_store=None, base=None):
+    """drq_conv1_aug_fwd_indexed: the two views are rows idx / idx1 (int64) of frame stores [slots, 9*84*84] uint8."""
+    lib = _lib.load()
+    n = idx.numel()
+    shift, shift1 = _need(shift.reshape(n, 2), name="shift"), _need(shift1.reshape(n, 2), name="shift1")
+    base = aug_base_grid(84, 4, frames.device) if base is None else _need(base, name="base")
+    n_store = n if n_store is None else n_store
+    y = torch.empty((2 * n, 32, 41, 41), device=frames.device, dtype=torch.float32)
+    xaug = torch.zeros((2 * n, 9, 84, 84), device=frames.device, dtype=torch.float32)
+    check(lib.drq_conv1_aug_fwd_indexed(ptr(frames), ptr(idx), ptr(shift), ptr(frames1), ptr(idx1), ptr(shift1), ptr(base),
+                                        ptr(_need(w, name="w")), ptr(_need(b, name="b")), ptr(xaug), ptr(y), n, n_store,
+                                        _stream()), "drq_conv1_aug_fwd_indexed")
+    return y, xaug
+
+
 def u8_normalize(x):
     lib = _lib.load()
     _need(x, torch.uint8, "obs")

@@ -19,8 +19,26 @@ from . import _lib
 from ._lib import check, ptr
 
 
+class IndexedBatch(tuple):
+    """A replay batch whose frames stay in the store: the 5-tuple (obs, action, reward, discount, next_obs) of the
+    reference's loader with obs / next_obs replaced by int64 index tensors [B] into `frames` (the store, [slots, frame
+    bytes] uint8).  DrQV2Agent.update() hands store + indices to the fused aug+conv1 launch, which gathers its source
+    rows itself: the 32.5 MB batch copy (and its re-read) of the materialised form never happens."""
+
+    def __new__(cls, frames, obs_idx, action, reward, discount, next_idx):
+        self = super().__new__(cls, (obs_idx, action, reward, discount, next_idx))
+        self.frames = frames
+        return self
+
+    def materialize(self, obs_shape):
+        """The batch as the reference's loader would hand it over: (obs, action, reward, discount, next_obs) tensors."""
+        obs_idx, action, reward, discount, next_idx = self
+        shp = (obs_idx.numel(),) + tuple(obs_shape)
+        return (self.frames[obs_idx].view(shp), action, reward, discount, self.frames[next_idx].view(shp))
+
+
 class DeviceReplay:
-    def __init__(self, capacity_steps, obs_shape, action_dim, nstep, discount, device, seed=None):
+    def __init__(self, capacity_steps, obs_shape, action_dim, nstep, discount, device, seed=None, indexed=False):
         self.device = torch.device(device)
         self.obs_shape = tuple(int(s) for s in obs_shape)
         self.frame_bytes = int(np.prod(self.obs_shape))
@@ -39,6 +57,10 @@ class DeviceReplay:
         self._head = 0              # next free slot
         self.rng = np.random.RandomState(seed)
         self._out = {}
+        # True: batches are IndexedBatch objects (frames stay in the store); False: materialised tensors like the
+        # reference's loader yields
+        self.indexed = bool(indexed)
+        self._ibufs = {}
 
     # ---- storage -------------------------------------------------------------------------
     def __len__(self):
@@ -112,8 +134,36 @@ class DeviceReplay:
         shp = (B,) + self.obs_shape
         return obs.view(shp), act, rew, disc, nxt.view(shp)
 
+    def gather_indexed(self, pos):
+        """pos: host int64 store indices [B] -> IndexedBatch: action rows and n-step reward / discount assembled by the
+        same kernel (its frame copies skipped), obs = frame pos-1, next_obs = frame pos+nstep-1 as indices."""
+        if self.device.type != "cuda":
+            raise _lib.DrqError("replay batch assembly runs on the GPU: the HIP path has no CPU fallback")
+        lib = _lib.load()
+        pos = np.ascontiguousarray(pos, np.int64)
+        B = pos.size
+        bufs = self._ibufs.get(B)
+        if bufs is None:
+            dev = self.device
+            # two sets, used alternately: the update that consumes batch k is still queued when batch k+1 is assembled
+            mk = lambda: (torch.empty((3, B), dtype=torch.int64, device=dev), torch.empty((B, self.A), dtype=torch.float32, device=dev),
+                          torch.empty((B, 1), dtype=torch.float32, device=dev), torch.empty((B, 1), dtype=torch.float32, device=dev),
+                          torch.empty((3, B), dtype=torch.int64).pin_memory())
+            bufs = [mk(), mk(), 0]
+            self._ibufs = {B: bufs}
+        idx, act, rew, disc, host = bufs[bufs[2]]
+        bufs[2] ^= 1
+        h = host.numpy()
+        h[0], h[1], h[2] = pos - 1, pos + self.nstep - 1, pos
+        idx.copy_(host, non_blocking=True)
+        check(lib.drq_nstep_gather(ptr(self.frames), ptr(self.action), ptr(self.reward), ptr(self.discount), ptr(idx[2]), B,
+                                   self.A, self.frame_bytes, self.nstep, self.gamma, None, ptr(act), ptr(rew), ptr(disc),
+                                   None, torch.cuda.current_stream().cuda_stream), "drq_nstep_gather")
+        return IndexedBatch(self.frames, idx[0], act, rew, disc, idx[1])
+
     def sample(self, batch_size):
-        return self.gather(self.draw_positions(batch_size))
+        pos = self.draw_positions(batch_size)
+        return self.gather_indexed(pos) if self.indexed else self.gather(pos)
 
     def __iter__(self):
         while True:

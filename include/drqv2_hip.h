@@ -51,6 +51,12 @@ int drq_conv1_aug_fwd(const uint8_t* obs, const float* shift, const uint8_t* obs
                       int n_store, drq_stream_t stream);
 /* the same with the layer's products on the bf16 MFMA (the bf16 update path, see the bf16 conv entries below): the
  * augmentation and the stored encoder input are the fp32 ones, bit for bit; y = relu(conv(bf16(x), bf16(w)) + b). */
+/* the same with the two views given as rows idx[b] / idx1[b] of frame stores (a device-resident replay ring): the batch
+ * of replay_buffer.py:142-160 is never materialised; results are bit-identical to drq_conv1_aug_fwd on the gathered
+ * frames. */
+int drq_conv1_aug_fwd_indexed(const uint8_t* frames, const int64_t* idx, const float* shift, const uint8_t* frames1,
+                              const int64_t* idx1, const float* shift1, const float* base_grid, const float* w,
+                              const float* bias, float* xaug, float* y, int n, int n_store, drq_stream_t stream);
 int drq_conv1_aug_fwd_bf16(const uint8_t* obs, const float* shift, const uint8_t* obs1, const float* shift1,
                            const float* base_grid, const float* w, const float* bias, float* xaug, float* y, int n,
                            int n_store, drq_stream_t stream);
@@ -302,6 +308,11 @@ typedef struct {
                               * the critic's optimiser step (the heads of the actor update).  Pairs beyond timing_n
                               * are not recorded. */
   int timing_n;              /* entries of timing_events (0, 4, 6, 8 or 10) */
+  const int64_t* obs_index;      /* optional (both or neither): the batch is NOT materialised -- `obs` / `next_obs` are */
+  const int64_t* next_obs_index; /* stores of frames (a device replay ring, [slots][C][84][84] u8) and row b of the batch
+                              * is frame obs_index[b] of `obs` / next_obs_index[b] of `next_obs` (replay_buffer.py:152-153:
+                              * idx-1 and idx+nstep-1).  The fused aug+conv1 launch gathers its source rows straight from
+                              * the store. */
   int flags;                 /* schedule switches for A/B measurements and for tests that hold both forms to the oracle:
                               * DRQ_STEP_NO_ROW_FUSION (1): LayerNorm / policy output layer / first MLP layers as separate
                               * launches (the round-2 schedule) instead of csrc/rowblock.hip's fused ones;

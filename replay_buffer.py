@@ -135,7 +135,7 @@ class _Loader:
 
 
 def make_replay_loader(replay_dir, max_size, batch_size, num_workers, save_snapshot, nstep, discount, device=None,
-                       obs_shape=None, action_dim=None, seed=None):
+                       obs_shape=None, action_dim=None, seed=None, indexed=False):
     """Same positional signature as the reference (replay_buffer.py:173-190).  The observation / action shapes
     come from the data_specs the storage of the same replay_dir was built with (or from the keyword arguments)."""
     ent = _entry(replay_dir)
@@ -150,7 +150,9 @@ def make_replay_loader(replay_dir, max_size, batch_size, num_workers, save_snaps
     capacity = int(max_size) + int(max_size) // 100 + 1024
     if seed is None:
         seed = int(np.random.get_state()[1][0])          # what the reference's _worker_init_fn seeds from
-    ent["store"] = DeviceReplay(capacity, obs_shape, action_dim, nstep, discount, device, seed=seed)
+    # indexed=True: the iterator yields drqv2_amd.replay.IndexedBatch objects (frames stay in the store, the update's first
+    # kernel gathers them): what DrQV2Agent.update() consumes fastest; False: plain device tensors like the reference's
+    ent["store"] = DeviceReplay(capacity, obs_shape, action_dim, nstep, discount, device, seed=seed, indexed=indexed)
     ent["save_snapshot"] = bool(save_snapshot)
     # resume: the newest episodes on disk that fit max_size (replay_buffer.py:120-140 walks them newest first),
     # added oldest first so that eviction order stays chronological

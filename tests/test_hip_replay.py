@@ -68,3 +68,55 @@ def test_update_consumes_device_batches(tmp_path):
         assert all(np.isfinite(v) for v in m.values()) and set(m) >= {"critic_loss", "actor_loss", "batch_reward"}
     batch = next(it)
     assert all(t.is_cuda for t in batch) and batch[0].dtype == torch.uint8 and batch[0].shape == (16,) + OBS
+
+
+def test_fused_aug_conv1_gathers_from_the_store_bit_for_bit():
+    """drq_conv1_aug_fwd_indexed (the two views given as rows of a frame store) against drq_conv1_aug_fwd on the
+    gathered frames: identical layer output and identical stored encoder input, every element."""
+    from drqv2_amd import ops
+    r = np.random.RandomState(0)
+    slots, n = 300, 37
+    frames = torch.from_numpy(r.randint(0, 256, (slots, 9 * 84 * 84)).astype(np.uint8)).cuda()
+    idx = torch.from_numpy(r.randint(0, slots, n).astype(np.int64)).cuda()
+    idx1 = torch.from_numpy(r.randint(0, slots, n).astype(np.int64)).cuda()
+    sh = torch.from_numpy(r.randint(0, 9, (n, 2)).astype(np.float32)).cuda()
+    sh1 = torch.from_numpy(r.randint(0, 9, (n, 2)).astype(np.float32)).cuda()
+    w = torch.from_numpy((r.randn(32, 9, 3, 3) * 0.2).astype(np.float32)).cuda()
+    b = torch.from_numpy((r.randn(32) * 0.1).astype(np.float32)).cuda()
+    obs = frames[idx].view(n, 9, 84, 84).contiguous()
+    obs1 = frames[idx1].view(n, 9, 84, 84).contiguous()
+    y0, x0 = ops.conv1_aug_fwd(obs, sh, obs1, sh1, w, b, n_store=2 * n)
+    y1, x1 = ops.conv1_aug_fwd_indexed(frames, idx, sh, frames, idx1, sh1, w, b, n_store=2 * n)
+    assert torch.equal(y0, y1) and torch.equal(x0, x1)
+
+
+def test_update_from_indexed_batches_equals_materialised_batches():
+    """IndexedBatch (frames stay in the store; obs / next_obs travel as indices) through DrQV2Agent.update(): the same
+    update as with the batch drq_nstep_gather materialises -- parameters, Adam moments and metrics bit for bit, three
+    updates, same index draws."""
+    import drqv2
+    from drqv2_amd.replay import DeviceReplay, IndexedBatch
+    A, B = 6, 64
+    outs = []
+    for indexed in (False, True):
+        rp = DeviceReplay(400, OBS, A, 3, 0.99, "cuda", seed=5, indexed=indexed)
+        for i, T in enumerate((40, 25, 60)):
+            rp.add_episode(episode(T, A, seed=20 + i))
+        rp.batch_size = B
+        torch.manual_seed(3)
+        ag = drqv2.DrQV2Agent(OBS, (A,), "cuda", 1e-4, 50, 1024, 0.01, 2000, 2, "linear(1.0,0.1,500000)", 0.3, True)
+        torch.manual_seed(11); torch.cuda.manual_seed_all(11)
+        it = iter(rp)
+        ms = [ag.update(it, 2 * u) for u in range(3)]
+        torch.cuda.synchronize()
+        b = next(it)
+        assert isinstance(b, IndexedBatch) == indexed
+        if indexed:
+            obs, act, rew, disc, nxt = b.materialize(OBS)
+            assert obs.shape == (B,) + OBS and obs.dtype == torch.uint8 and rew.shape == (B, 1)
+        eng = ag._engine
+        outs.append((ms, eng.params.clone(), eng.adam_m.clone(), eng.adam_v.clone()))
+    (m0, *a0), (m1, *a1) = outs
+    assert m0 == m1
+    for x, y in zip(a0, a1):
+        assert torch.equal(x, y)

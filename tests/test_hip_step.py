@@ -685,6 +685,80 @@ def test_two_rank_update_with_direct_exchange(exchange):
     _run_two_ranks("gloo", exchange)
 
 
+def _zero1_gpu_worker(rank, world, port, cfg, ret, backend):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rep, zer = make_agent(cfg), make_agent(cfg)
+        try:
+            rep.enable_data_parallel(batch_is_global=True, exchange="direct")
+            zer.enable_data_parallel(batch_is_global=True, exchange="zero1")
+            ms = []
+            for u in range(3):
+                m_r, _, _ = run_hip(rep, cfg, u)
+                m_z, _, _ = run_hip(zer, cfg, u)
+                ms.append((m_r, m_z))
+            rep.flush(); zer.flush()
+            torch.cuda.synchronize()
+        except RuntimeError as e:                    # a gloo build without all-to-all for device tensors
+            ret[rank] = "unsupported: " + str(e)[:80]
+            return
+        er, ez = rep._engine, zer._engine
+        ok = torch.equal(er.params, ez.params)                          # weights AND the Polyak target, every rank
+        lay = er.layout["seg"]
+        own_ok = True
+        for net in ("enc", "critic", "actor"):
+            b, e = lay[net]
+            ns = (e - b) // world
+            sl = slice(b + rank * ns, b + (rank + 1) * ns)
+            own_ok &= torch.equal(er.adam_m[sl], ez.adam_m[sl]) and torch.equal(er.adam_v[sl], ez.adam_v[sl])
+        ez.gather_optimizer_state()                                     # what a snapshot does first
+        torch.cuda.synchronize()
+        full_ok = all(torch.equal(er.adam_m[lay[n][0]:lay[n][1]], ez.adam_m[lay[n][0]:lay[n][1]]) and
+                      torch.equal(er.adam_v[lay[n][0]:lay[n][1]], ez.adam_v[lay[n][0]:lay[n][1]])
+                      for n in ("enc", "critic", "actor"))
+        same_metrics = all(a == b for a, b in ms)
+        ret[rank] = "ok" if (ok and own_ok and full_ok and same_metrics) else f"mismatch {ok} {own_ok} {full_ok} {same_metrics}"
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_zero1(backend):
+    import socket
+    import torch.multiprocessing as mp
+    cfg = dict(CASES["small_h64_b6"]); cfg["B"] = 8
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_zero1_gpu_worker, args=(2, port, cfg, ret, backend), nprocs=2, join=True)
+    assert sorted(ret.keys()) == [0, 1]
+    if any(str(v).startswith("unsupported") for v in ret.values()):
+        pytest.skip(str(ret[0]))
+    assert dict(ret) == {0: "ok", 1: "ok"}
+
+
+def test_two_rank_zero1_equals_replicated_adam_bit_for_bit():
+    """ZeRO-1 (exchange="zero1": gradient slices by all-to-all, rank-order sum + Adam on the owned slice in one kernel,
+    stepped parameters by all-gather, Polyak on the gathered critic) against the replicated path with the same
+    rank-order sum ("direct"): after three updates of the overlapped schedule every parameter and the target are
+    bit-identical on every rank, each rank's own slice of the Adam moments too, and gather_optimizer_state() makes the
+    moments complete.  Two ranks share the box's GPU through gloo."""
+    _run_zero1("gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI)")
+def test_two_rank_rccl_zero1_equals_replicated_adam():
+    _run_zero1("nccl")
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI)")
 @pytest.mark.parametrize("exchange", ["allreduce", "direct"])
 def test_two_rank_rccl_update_equals_full_batch(exchange):
