@@ -295,12 +295,17 @@ __device__ __forceinline__ void gemm3_body(const G3Args& g, int tile, int batch,
       if constexpr (WK == 1) __builtin_amdgcn_s_barrier();      // operand reads of the last tile are done
       if (writer) {
         const float wv = g.qw[batch][n];
+        float p[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float p = v[r] * wv;
+        for (int r = 0; r < 16; ++r) p[r] = v[r] * wv;
+        // sixteen independent butterflies, step by step: the cross-lane moves of a step are in flight together
 #pragma unroll
-          for (int o = 1; o < 32; o <<= 1) p += __shfl_xor(p, o);
-          if (i == 0) qred[(wm * WN + wn) * 32 + rowmap3(r, h)] = p;
+        for (int o = 1; o < 32; o <<= 1)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) p[r] += __shfl_xor(p[r], o);
+        if (i == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) qred[(wm * WN + wn) * 32 + rowmap3(r, h)] = p[r];
         }
       }
       __syncthreads();
@@ -412,7 +417,7 @@ int drq_gemm3_fwd(int nbatch, const float* const* A, long lda, const float* cons
 #endif
   // enough 64x64 tiles to give every CU one: one sub-tile per wave; else 64x32 tiles with the k-steps of a k-tile
   // split over two wave groups (twice the workgroups, half the MFMAs per wave)
-  if (t64 >= drq_num_cus() || qw) {
+  if (t64 >= drq_num_cus()) {
     if (nq_out) *nq_out = N / 64;
     hipLaunchKernelGGL((gemm3_kernel<0, 2, 2, 1, 6>), dim3((M / 64) * (N / 64), 1, nbatch), dim3(256), 0, st, g);
   } else {
