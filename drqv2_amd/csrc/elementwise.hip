@@ -748,6 +748,11 @@ __global__ __launch_bounds__(1024) void qout_bwd_kernel(QOutBwdArgs a) {
   const float* h = a.h[z];
   float* dh = a.dh[z];
   const float wn = a.w[z][nc];
+  // the first 16 rows of h of this thread do not depend on dq: requested now, so that their round trip overlaps the
+  // dq stage's (a kernel of this size is a chain of dependent memory round trips; every load issued late is one more)
+  float hv0[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) hv0[u] = h[(long)min(rg + 16 * u, a.B - 1) * a.H + nc];
   if (a.td == 2) {
     const float *qz = z == 0 ? a.q1 : a.q2, *qo = z == 0 ? a.q2 : a.q1;
     const float g = -a.invB;
@@ -770,7 +775,7 @@ __global__ __launch_bounds__(1024) void qout_bwd_kernel(QOutBwdArgs a) {
   for (int m0 = rg; m0 < a.B; m0 += 16 * 16) {
     float hv[16];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) hv[u] = h[(long)min(m0 + 16 * u, a.B - 1) * a.H + nc];
+    for (int u = 0; u < 16; ++u) hv[u] = m0 == rg ? hv0[u] : h[(long)min(m0 + 16 * u, a.B - 1) * a.H + nc];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       const int m = m0 + 16 * u;
@@ -1030,6 +1035,10 @@ __global__ __launch_bounds__(1024) void policy_out_bwd_kernel(PolBwdArgs a) {
   const int n = blockIdx.x * 64 + c;
   const bool nok = n < a.H;
   const int nc = nok ? n : a.H - 1;
+  // first batch of p2 rows: independent of dpre, requested before the dpre stage (see qout_bwd_kernel)
+  float hv0[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) hv0[u] = a.p2[(long)min(rg + 16 * u, a.B - 1) * a.H + nc];
   for (int i = threadIdx.x; i < a.B * a.A; i += 1024) {
     const int m = i / a.A, j = i - m * a.A;
     const float mv = a.mu[i];
@@ -1054,7 +1063,7 @@ __global__ __launch_bounds__(1024) void policy_out_bwd_kernel(PolBwdArgs a) {
   for (int m0 = rg; m0 < a.B; m0 += 16 * 16) {
     float hv[16];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) hv[u] = a.p2[(long)min(m0 + 16 * u, a.B - 1) * a.H + nc];
+    for (int u = 0; u < 16; ++u) hv[u] = m0 == rg ? hv0[u] : a.p2[(long)min(m0 + 16 * u, a.B - 1) * a.H + nc];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       const int m = m0 + 16 * u;

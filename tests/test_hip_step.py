@@ -595,7 +595,14 @@ def _dp2_worker(rank, world, port, cfg, ret, backend="gloo", exchange="allreduce
             torch.cuda.synchronize()
             g_dp, g_1 = ag._engine.grads, ref._engine.grads
             lay = ag._engine.layout["seg"]
-            errs = {n: nerr(g_dp[lay[n][0]:lay[n][1]], g_1[lay[n][0]:lay[n][1]]) for n in ("enc", "critic", "actor")}
+            def summed(n):      # a bucket that took the sharded step ("auto" may pick it) keeps this rank's share in the
+                b, e = lay[n]   # arena: the sum only ever existed inside the exchange, so it is formed here
+                g = g_dp[b:e]
+                if ag._engine.exchange is not None and ag._engine.exchange.sharded(e - b):
+                    g = g.clone()
+                    dist.all_reduce(g, op=dist.ReduceOp.SUM)
+                return g
+            errs = {n: nerr(summed(n), g_1[lay[n][0]:lay[n][1]]) for n in ("enc", "critic", "actor")}
             out[u] = (m_dp, m_1, errs)
         # parameters: Adam's first steps are sign-like, so compare through the update direction's agreement
         d_dp = ag._engine.params - make_agent(cfg)._engine.params
