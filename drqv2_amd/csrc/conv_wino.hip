@@ -176,7 +176,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   // units instead of 2q + 1 or 2q + 2 -- the two workgroups of a CU are blockIdx b and b + 256, so the waves
   // [0, 1024) sit on distinct SIMDs); with 2r > nwave the first nf = 2r - nwave waves take a whole unit, every other
   // wave a half.  Results do not depend on the split (the same MFMAs in the same order per accumulator).
-  const int gw = blockIdx.x * 4 + wid;
+  // Workgroup -> position in a round, XCD-aware: the hardware deals workgroups to the eight XCDs round-robin
+  // (blockIdx & 7; a speed assumption only), and neighbouring workgroups of a round read neighbouring tile rows, which
+  // share two of their four input rows.  With the plain order those re-reads came from eight different L2s (1.5x the
+  // compulsory fabric traffic); here each half of the grid (one workgroup per CU) gives every XCD a contiguous
+  // eighth of the round, and the two halves stay as they are (see the left-over rule below).
+  const int hg = (int)gridDim.x >> 1;
+  const int bh = (int)blockIdx.x >= hg ? 1 : 0, bl = (int)blockIdx.x - bh * hg;
+  const int lb = ((int)gridDim.x & 15) ? (int)blockIdx.x : bh * hg + (bl & 7) * (hg >> 3) + (bl >> 3);
+  const int gw = lb * 4 + wid;
   const int q = nunit / nwave, r = nunit - q * nwave;
   const int nf = 2 * r > nwave ? 2 * r - nwave : 0;
   const int nfull = q + (gw < nf ? 1 : 0);

@@ -274,7 +274,8 @@ __device__ __forceinline__ void ww_body(const WWArgs& a, int bx, int nblk) {
 
 template <int HIN, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_wino_kernel(WWArgs a) {
-  ww_body<HIN, ABL>(a, (int)blockIdx.x, (int)gridDim.x);
+  const int G = (int)gridDim.x;   // XCD-aware order, see conv3x3_wgrad_wino3_kernel
+  ww_body<HIN, ABL>(a, (G & 7) ? (int)blockIdx.x : ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3), G);
 }
 
 // The three 32->32 layers of the encoder backward in ONE launch: layer l owns workgroups [beg[l], beg[l+1]) of the
@@ -285,7 +286,12 @@ struct WW3Args {
   int beg[4];
 };
 __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_wino3_kernel(WW3Args g) {
-  const int b = (int)blockIdx.x;
+  // XCD-aware order (workgroups go to the eight XCDs round-robin by blockIdx; speed only): every XCD takes a contiguous
+  // eighth of the grid, so that the workgroups which read neighbouring steps of a round -- 40 of 128 bytes of a line
+  // horizontally, two of four input rows vertically -- share an L2 instead of pulling each line through the fabric once
+  // per XCD
+  const int G = (int)gridDim.x;
+  const int b = (G & 7) ? (int)blockIdx.x : ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3);
   if (b < g.beg[1]) ww_body<41>(g.l[0], b, g.beg[1]);
   else if (b < g.beg[2]) ww_body<39>(g.l[1], b - g.beg[1], g.beg[2] - g.beg[1]);
   else ww_body<37>(g.l[2], b - g.beg[2], g.beg[3] - g.beg[2]);
