@@ -34,6 +34,16 @@ typedef unsigned u32x2q __attribute__((ext_vector_type(2)));
 
 #ifdef DRQ_DEV
 int g_ww_variant = 0;   // drq_dev_wgrad_wino_variant: timing ablations (tools/wino_ab.py)
+// drq_dev_wgrad_wino_stamps: 8 u64 per wave (s_memtime at start / first patches issued / loop done / image in LDS /
+// after the barrier / record written, then s_memrealtime start and end); tools/wwino_stamps.py
+__device__ unsigned long long* d_ww_stamps = nullptr;
+#define WW_MARK(k)                                                                                                     \
+  do {                                                                                                                 \
+    if (d_ww_stamps && lane == 0) d_ww_stamps[((size_t)bx * 4 + wid) * 8 + (k)] =                                       \
+        (k) >= 6 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();                                    \
+  } while (0)
+#else
+#define WW_MARK(k)
 #endif
 
 // ABL (development build only): 1 = no patch loads, 2 = no transforms (the raw patches are multiplied); wrong results
@@ -49,6 +59,8 @@ __device__ __forceinline__ void ww_body(const WWArgs& a, int bx, int nblk) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][PART]
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ch = lane & 15, tq = lane >> 4;
+  WW_MARK(6);
+  WW_MARK(0);
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
   constexpr int kDrop = (int)0x80000000u;     // beyond num_records: the load returns 0
@@ -214,7 +226,9 @@ __device__ __forceinline__ void ww_body(const WWArgs& a, int bx, int nblk) {
     item_off(0, xo, dyo);
     load_item(dx0, dy0, xo, dyo);
   }
+  WW_MARK(1);
   for (int it = 0; it < total; ++it) step(dx0, dy0, it + 1);
+  WW_MARK(2);
 
   // ---- dg = G^T dU G per (cout, cin) -> this wave's image of the partial record in LDS
   // D register r of lane l: cout = 16*qa + 4*(l>>4) + r, cin = 16*qb + (l&15)
@@ -262,7 +276,9 @@ __device__ __forceinline__ void ww_body(const WWArgs& a, int bx, int nblk) {
       mine[9 * 1024 + 48 + ch] = 0.f;
     }
   }
+  WW_MARK(3);
   __syncthreads();
+  WW_MARK(4);
   float4* out = reinterpret_cast<float4*>(a.part + (long)bx * PART);
   const float4* r4 = reinterpret_cast<const float4*>(red);
   for (int i = threadIdx.x; i < PART / 4; i += 256) {
@@ -270,6 +286,11 @@ __device__ __forceinline__ void ww_body(const WWArgs& a, int bx, int nblk) {
     out[i] = make_float4((p.x + q.x) + (v.x + w.x), (p.y + q.y) + (v.y + w.y), (p.z + q.z) + (v.z + w.z),
                          (p.w + q.w) + (v.w + w.w));
   }
+#ifdef DRQ_DEV
+  if (d_ww_stamps) __builtin_amdgcn_s_waitcnt(0);
+#endif
+  WW_MARK(5);
+  WW_MARK(7);
 }
 
 template <int HIN, int ABL = 0>
@@ -337,6 +358,9 @@ int launch_ww(const WWArgs& a, int* nblocks, hipStream_t st) {
 
 #ifdef DRQ_DEV
 extern "C" DRQ_API void drq_dev_wgrad_wino_variant(int v) { g_ww_variant = v; }
+extern "C" DRQ_API void drq_dev_wgrad_wino_stamps(unsigned long long* p) {
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(d_ww_stamps), &p, sizeof(p));
+}
 #endif
 
 // internal (step.hip): conv2, conv3, conv4 (hin 41, 39, 37) in one launch; x[l], dy[l], part[l] and the dY strides per
