@@ -178,6 +178,8 @@ class Runner:
         self.dtype = dtype
         if dtype == "bf16":
             self.agent.set_compute_dtype("bf16")
+        if os.environ.get("DRQ_BENCH_METRICS_SPIN"):     # A/B of the metrics wait only (tools/): polls before sleeping
+            self.agent._engine.metrics_spin = int(os.environ["DRQ_BENCH_METRICS_SPIN"])
         if dp:
             self.agent.enable_data_parallel(batch_is_global=False, exchange=exchange)
         batch = synth.make_batch(B_local, A, 9, seed=rank, smooth=True)

@@ -317,6 +317,7 @@ class StepEngine:
         self._timing_n = 0
         self.step_flags = 0       # DrqStep.flags: 1 = no row fusion, 2 = no gemm3 (A/B measurements, both-form tests)
         self.metrics_spin = 256         # read_sums(): polls of the host mirror before the waiting thread starts to sleep
+        self.metrics_wait_est = None    # read_sums(): running estimate (s) of how long the sums take to arrive
         self.profile_exchange = False   # bench.py: event pairs around every wait for a gradient exchange
         self.exchange_wait_us = {}      # bucket name -> [us the compute stream waited], see collect_exchange_waits()
         self._wait_events = []
@@ -736,22 +737,34 @@ class StepEngine:
         want = self._last_seq if self._last_seq < 2 ** 31 else self._last_seq - 2 ** 32
         seq = self._sums_seq
         import time
-        # A short spin (the sums usually land within tens of microseconds of the call when the host runs ahead of the
-        # GPU), then sleeps with a back-off: the host thread shares its core with the simulator in train.py, and the
-        # update's tail (actor backward, Adam, Polyak: ~150 us) still hides a late wake-up.
+        # The wait is ~0.8 ms at batch 256 and the same from one update to the next, so the thread does not poll through
+        # it: a short spin (the sums are there already when the host lags the GPU), then ONE sleep that ends a safe
+        # margin before the sums are due (running estimate of the last waits), then polling for the last stretch.
+        # Sleeping in short naps until the sums show up (the first version of this) woke up late often enough to cost
+        # 3 % of the bench (a tenth of the updates 0.1 ms late: the next update reached the GPU after the previous one's
+        # tail had drained); polling all the way keeps a host core busy that train.py's simulator wants.
+        t_in = time.perf_counter()
         spins = 0
         while int(seq) != want and spins < self.metrics_spin:
             spins += 1
         if int(seq) != want:
-            t0 = time.monotonic()
-            nap = 20e-6
+            est = self.metrics_wait_est
+            if est is not None and est > 300e-6:
+                time.sleep(est - max(200e-6, 0.25 * est))
+                if int(seq) == want:             # overslept (the estimate was too long): shorten it, no sample
+                    self.metrics_wait_est = 0.8 * est
+                    return self.sums_host[:8].tolist()
+            limit = (est or 0.0) + 2e-3
             while int(seq) != want:
-                time.sleep(nap)
-                nap = min(nap * 1.5, 60e-6)      # a late wake-up must stay inside the update's ~150 us tail
-                if time.monotonic() - t0 > 30.0:
-                    torch.cuda.synchronize()               # surfaces a device fault, if that is why nothing arrived
-                    if int(seq) != want:
-                        raise _lib.DrqError("metric sums of the update never arrived in the host mirror")
+                waited = time.perf_counter() - t_in
+                if waited > limit:               # unusually long (first update, another process on the GPU): nap
+                    time.sleep(50e-6)
+                    if waited > 30.0:
+                        torch.cuda.synchronize()           # surfaces a device fault, if that is why nothing arrived
+                        if int(seq) != want:
+                            raise _lib.DrqError("metric sums of the update never arrived in the host mirror")
+            waited = time.perf_counter() - t_in
+            self.metrics_wait_est = waited if est is None else 0.75 * est + 0.25 * waited
         return self.sums_host[:8].tolist()
 
     def act_forward(self, obs_u8):
