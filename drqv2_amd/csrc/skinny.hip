@@ -29,6 +29,7 @@ struct SkinnyD {
   int scatter_hw;     // >0: padded (pad 2) NCHW scatter of column n = (ch, y, x), see gemm.hip
   unsigned c_bytes, aux_bytes;
   int mt_per_block;   // 32-row tiles of M per workgroup
+  int nrowblk, ncolblk;
 };
 
 // KP = k pairs kept in registers (K <= 2*KP)
@@ -39,7 +40,12 @@ __global__ __launch_bounds__(256, (KP <= 32 ? 5 : 2)) void skinny_dgrad_kernel(S
   const int MP = MB + 33;          // pitch = 33 mod 64 when MB % 64 == 0: conflict-free transposing writes
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int col = lane & 31, half = lane >> 5;
-  const int mbase = blockIdx.y * MB;
+  // one-dimensional grid, XCD-aware (workgroups go to the XCDs round-robin by blockIdx; speed only): the row blocks of
+  // one column block -- they read the same W[:, 128 columns] -- are 8 apart in blockIdx and so share an L2
+  const int L = (int)blockIdx.x, xs = L >> 3;
+  const int rowblk = xs % g.nrowblk, colblk = (xs / g.nrowblk) * 8 + (L & 7);
+  if (colblk >= g.ncolblk) return;                         // padding of the grid (whole workgroups)
+  const int mbase = rowblk * MB;
 
   // stage dz rows [mbase, mbase+MB) transposed, zero outside the matrix
   for (int idx = tid; idx < MB * 2 * KP; idx += 256) {
@@ -48,7 +54,7 @@ __global__ __launch_bounds__(256, (KP <= 32 ? 5 : 2)) void skinny_dgrad_kernel(S
     lds[k * MP + m] = ok ? g.dz[(long)(mbase + m) * g.lda + k] : 0.f;
   }
 
-  const int n = (blockIdx.x * 4 + wid) * 32 + col;
+  const int n = (colblk * 4 + wid) * 32 + col;
   const bool nok = n < g.N;
   const int nc = nok ? n : g.N - 1;
   float wv[KP];
@@ -120,12 +126,14 @@ int drq_skinny_dgrad(const float* dz, long lda, const float* w, long ldb, float*
   const long crow = scatter_hw > 0 ? 32L * (scatter_hw + 4) * (scatter_hw + 4) : ldc;
   const size_t cb = (size_t)M * crow * 4, ab = aux ? (size_t)M * ldaux * 4 : 0;
   if (cb >= (1ull << 31) || ab >= (1ull << 31)) return DRQ_EARG;
-  SkinnyD g{dz, w, aux, c, lda, ldb, ldc, ldaux, M, N, K, scatter_hw, (unsigned)cb, (unsigned)ab, 0};
+  SkinnyD g{dz, w, aux, c, lda, ldb, ldc, ldaux, M, N, K, scatter_hw, (unsigned)cb, (unsigned)ab, 0, 0, 0};
   const int mtiles = (M + 31) / 32;
   g.mt_per_block = mtiles >= 4 ? 2 : mtiles;     // 4 workgroups along M at B = 256: ~5 waves per SIMD
   if (K > 64 && g.mt_per_block > 2) g.mt_per_block = 2;   // dynamic LDS stays under 64 KB
   const int MB = g.mt_per_block * 32;
-  dim3 grid((N / 32 + 3) / 4, (mtiles + g.mt_per_block - 1) / g.mt_per_block);
+  g.ncolblk = (N / 32 + 3) / 4;
+  g.nrowblk = (mtiles + g.mt_per_block - 1) / g.mt_per_block;
+  dim3 grid((unsigned)(8 * g.nrowblk * ((g.ncolblk + 7) / 8)));
   // the two feature dimensions of the reference's configs (50, 100) get exact register tiles
   const int kp = K == 50 ? 25 : K <= 64 ? 32 : K == 100 ? 50 : 64;
   const size_t lds = (size_t)2 * kp * (MB + 33) * 4;
