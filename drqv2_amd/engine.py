@@ -309,6 +309,7 @@ class StepEngine:
         self.sums_host = torch.zeros(16, dtype=torch.float32).pin_memory() if dev.type == "cuda" else None
         self._sums_seq = self.sums_host[8:9].view(torch.int32) if self.sums_host is not None else None
         self._last_seq = None
+        self._enqueued = []             # sequence words of the last two updates handed to the GPU (_throttle)
         self.pg = None            # torch.distributed process group for data parallelism
         self._pending = None      # (all-reduce handle, descriptor, tensors kept alive) of a deferred Adam(actor)
         self._pending_enc = None  # the same for Adam(encoder)
@@ -602,6 +603,7 @@ class StepEngine:
         d.shift_obs, d.shift_next = ptr(shift_obs), ptr(shift_next)
         d.noise_critic, d.noise_actor = ptr(noise_critic), ptr(noise_actor)
         if self.pg is None:
+            self._throttle(steps[2] & 0xFFFFFFFF)
             self._phase(d, -1)
             self._last_seq = steps[2] & 0xFFFFFFFF
         else:
@@ -726,6 +728,32 @@ class StepEngine:
         self._last_seq = None
         self._manual = None
         return self.sums
+
+    def _throttle(self, seq):
+        """Single GPU: at most two updates are queued behind the one the GPU works on.  A caller that never reads the
+        metrics (use_tb=False, metrics_on_device) would otherwise run the host as far ahead as the HIP queue lets it --
+        nothing gained (the GPU is the bottleneck), and every host-side staging buffer that feeds the updates (the
+        device replay's pinned index sets, drqv2_amd/replay.py) would have to be as deep as that queue.  With the metrics
+        read every update this never waits: the previous update has published by then.  `seq`: this update's
+        sequence word (its actor step count), the mirror shows the last one published."""
+        if self._sums_seq is None:
+            return
+        q = self._enqueued
+        if q and ((q[-1] + 1) & 0xFFFFFFFF) != seq:          # step counts were set from outside (snapshot): start over
+            q.clear()
+        if len(q) >= 2:
+            import time
+            t0 = None
+            while (int(self._sums_seq) & 0xFFFFFFFF) not in q:   # neither of the last two has published its sums yet
+                if t0 is None:
+                    t0 = time.monotonic()
+                time.sleep(100e-6)
+                if time.monotonic() - t0 > 30.0:
+                    torch.cuda.synchronize()                     # surfaces a device fault
+                    if (int(self._sums_seq) & 0xFFFFFFFF) not in q:
+                        raise _lib.DrqError("update(): the updates queued before this one never published their sums")
+        q.append(seq)
+        del q[:-2]
 
     def read_sums(self):
         """The 8 metric sums of the last update as Python floats.  Single GPU: waits only until the update has

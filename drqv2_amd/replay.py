@@ -145,14 +145,17 @@ class DeviceReplay:
         bufs = self._ibufs.get(B)
         if bufs is None:
             dev = self.device
-            # two sets, used alternately: the update that consumes batch k is still queued when batch k+1 is assembled
+            # four sets, used in turn.  The device tensors are written in stream order (no hazard), but the pinned host
+            # staging of set s is overwritten by the HOST when batch k+4 is drawn, and its upload must have run by then:
+            # StepEngine.update keeps at most two updates queued behind the running one (_throttle), so three batches
+            # can be pending at most.  A consumer of its own must bound its run-ahead likewise (or use gather()).
             mk = lambda: (torch.empty((3, B), dtype=torch.int64, device=dev), torch.empty((B, self.A), dtype=torch.float32, device=dev),
                           torch.empty((B, 1), dtype=torch.float32, device=dev), torch.empty((B, 1), dtype=torch.float32, device=dev),
                           torch.empty((3, B), dtype=torch.int64).pin_memory())
-            bufs = [mk(), mk(), 0]
+            bufs = [mk(), mk(), mk(), mk(), 0]
             self._ibufs = {B: bufs}
-        idx, act, rew, disc, host = bufs[bufs[2]]
-        bufs[2] ^= 1
+        idx, act, rew, disc, host = bufs[bufs[4]]
+        bufs[4] = (bufs[4] + 1) & 3
         h = host.numpy()
         h[0], h[1], h[2] = pos - 1, pos + self.nstep - 1, pos
         idx.copy_(host, non_blocking=True)

@@ -120,3 +120,37 @@ def test_update_from_indexed_batches_equals_materialised_batches():
     assert m0 == m1
     for x, y in zip(a0, a1):
         assert torch.equal(x, y)
+
+
+def test_indexed_batches_without_metrics_reads_host_running_ahead():
+    """use_tb=False: update() returns without reading the metrics, so nothing but StepEngine._throttle keeps the host
+    from drawing batch after batch while the GPU is still on the first -- and the device replay stages its index lists
+    in four pinned host sets that it re-uses.  Forty updates, back to back, must leave exactly the state of the same
+    forty updates issued with the metrics read every time (bit for bit), and the engine never holds more than two
+    updates behind the running one."""
+    import drqv2
+    from drqv2_amd.replay import DeviceReplay
+    A, B, N = 6, 64, 40
+    outs = []
+    for use_tb in (True, False):
+        rp = DeviceReplay(400, OBS, A, 3, 0.99, "cuda", seed=5, indexed=True)
+        for i, T in enumerate((40, 25, 60)):
+            rp.add_episode(episode(T, A, seed=20 + i))
+        rp.batch_size = B
+        torch.manual_seed(3)
+        ag = drqv2.DrQV2Agent(OBS, (A,), "cuda", 1e-4, 50, 1024, 0.01, 2000, 2, "linear(1.0,0.1,500000)", 0.3, use_tb)
+        torch.manual_seed(11); torch.cuda.manual_seed_all(11)
+        it = iter(rp)
+        depth = 0
+        for u in range(N):
+            m = ag.update(it, 2 * u)
+            assert (m == {}) == (not use_tb)
+            eng = ag._engine
+            pub = int(eng._sums_seq) & 0xFFFFFFFF
+            last = eng._enqueued[-1]
+            depth = max(depth, (last - pub) & 0xFFFFFFFF if pub else 0)
+        torch.cuda.synchronize()
+        assert depth <= 3, depth          # the one running + two queued
+        outs.append((eng.params.clone(), eng.adam_m.clone(), eng.adam_v.clone()))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
