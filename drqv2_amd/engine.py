@@ -614,6 +614,8 @@ class StepEngine:
             (c0, c1), (e0, e1), (a0, a1) = grad_buckets_overlap(self.layout)
             mirror = self.sums_host is not None
             seq = steps[2] & 0xFFFFFFFF
+            if mirror:
+                self._throttle(seq)                             # the host stays at most two updates ahead
             if self._side_busy:                                 # the previous update's sums exchange owns self.sums
                 torch.cuda.current_stream(self.device).wait_stream(self._side)
                 self._side_busy = False
