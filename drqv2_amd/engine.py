@@ -582,6 +582,9 @@ class StepEngine:
                 if (t.dtype != torch.uint8 or not t.is_contiguous() or t.numel() % (self.C * 84 * 84) or
                         ix is None or ix.dtype != torch.int64 or ix.numel() != B or not ix.is_contiguous()):
                     raise _lib.DrqError(f"update(): indexed {nm}: a contiguous uint8 frame store and {B} int64 indices")
+                if not (ix.is_cuda or ix.is_pinned()):       # a pageable host pointer would fault on the GPU
+                    raise _lib.DrqError(f"update(): indexed {nm}: the index list must be a device tensor or PINNED host "
+                                        "memory")
         else:
             B = obs.shape[0]
         for nm, t in ((("obs", obs), ("next_obs", next_obs)) if not indexed else ()):
