@@ -21,12 +21,22 @@
 // consecutive pixels of an output row per MFMA.  A wave stages one (sample, output row) at a time into wave-private
 // LDS as bf16 in [channel][x] order; a lane's A fragment is 8 consecutive pixels of its cout (one ds_read_b128), and
 // the three kx taps of an input row come from ONE aligned 5-dword read (v_alignbit for the odd shift).
+//
+// Activation layouts.  LAY = 0: fp32 NCHW in and out (the C ABI entries; operands rounded as they are staged).  The
+// update's bf16 path keeps the activations BETWEEN the encoder layers (conv1..conv3 outputs) as bf16 in
+// [frame][y][x][32 channels] order, 64 bytes per pixel -- the order of the LDS image below.  The stage of the next layer
+// is then a straight copy of 16-byte pieces, a lane's sixteen outputs (channels 8g + 4*half + 0..3, g = 0..3, in the
+// 32x32 MFMA's C layout) are four 8-byte stores, and the ReLU mask of an input gradient four 8-byte loads.  Rounding at
+// the store instead of at the stage gives the same operands in the same k order: results are identical bit for bit
+// (round-to-nearest is monotone, so it commutes with ReLU and keeps the sign the mask tests); tests compare with LAY = 0.
+// LAY bits: 1 = input in that layout, 2 = output in that layout, 4 = mask in that layout.
 #include "common.h"
 
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2b __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {      // RNE, lo in bits 15:0
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -58,8 +68,9 @@ struct ConvBfGeom {
   static constexpr int LDS_DWORDS = NIN * PIXP > 18 * 64 * 4 ? NIN * PIXP : 18 * 64 * 4;
 };
 
-template <int HIN, bool MASK>
+template <int HIN, bool MASK, int LAY = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvBfArgs a) {
+  constexpr bool IN_NHWC = (LAY & 1) != 0, OUT_NHWC = (LAY & 2) != 0, MASK_NHWC = (LAY & 4) != 0;
   using G = ConvBfGeom<HIN>;
   constexpr int HOUT = G::HOUT, RP = G::RP, P = HOUT * HOUT;
   extern __shared__ __attribute__((aligned(16))) unsigned smem_u[];
@@ -107,6 +118,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvBfArgs a) {
     const int nin = (R + 2) * HIN;
     const float* src = a.x + ((long)b * 32 * HIN + r0) * HIN;      // channel 0, row r0
     __syncthreads();                                               // weights read / previous unit's tiles done
+    if constexpr (IN_NHWC) {
+      // ---- stage: the part's rows are nin * 64 contiguous bytes in exactly the image's order: 16-byte pieces
+      const u32x4* s4 = reinterpret_cast<const u32x4*>(a.x) + ((long)b * HIN + r0) * HIN * 4;
+      for (int i = tid; i < nin * 4; i += 256)
+        *reinterpret_cast<u32x4*>(smem_u + (i >> 2) * PIXP + (i & 3) * 4) = s4[i];
+    } else
     // ---- stage: pixels [0, nin) of every channel (contiguous per channel) -> bf16 [pixel][channel]
     for (int q0 = 0; q0 < nin; q0 += 256) {
       const int q = q0 + tid;
@@ -140,7 +157,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvBfArgs a) {
       for (int r = 0; r < 16; ++r) acc[r] = breg[r];
       float mv[16];
       const int oy = r0 + oyl;
-      if constexpr (MASK) {
+      if constexpr (MASK && MASK_NHWC) {       // the lane's channels 8g + 4*half + 0..3: 8 bytes at 16g + 8*half of the pixel
+        const int moff = ((b * P + oy * HOUT + ox) * 16 + half * 2) * 4;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const u32x2b m = __builtin_amdgcn_raw_buffer_load_b64(mrsrc, moff, g4 * 16, 0);
+          const unsigned w0 = m[0], w1 = m[1];
+          mv[4 * g4 + 0] = __uint_as_float(w0 << 16);
+          mv[4 * g4 + 1] = __uint_as_float(w0 & 0xffff0000u);
+          mv[4 * g4 + 2] = __uint_as_float(w1 << 16);
+          mv[4 * g4 + 3] = __uint_as_float(w1 & 0xffff0000u);
+        }
+      } else if constexpr (MASK) {
         const int moff = ((b * 32 + 4 * half) * P + oy * HOUT + ox) * 4;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -156,6 +184,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvBfArgs a) {
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t * 2 + g], xv, acc, 0, 0, 0);
         }
       }
+      if constexpr (OUT_NHWC) {                // channels 8g + 4*half + 0..3: 8 bytes at 16g + 8*half of the pixel
+        const int yoff = p0 < npix ? ((b * P + oy * HOUT + ox) * 16 + half * 2) * 4 : (int)0x80000000u;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = acc[4 * g4 + e];
+            if (a.relu) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            if constexpr (MASK) v[e] = mv[4 * g4 + e] > 0.f ? v[e] : 0.f;
+          }
+          const u32x2b o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+          __builtin_amdgcn_raw_buffer_store_b64(o, yrsrc, yoff, g4 * 16, 0);
+        }
+        continue;
+      }
       const int yoff = p0 < npix
                            ? ((int)a.y_off + b * (int)a.y_bs + oy * (int)a.y_rs + ox) * 4 + half * 4 * ycs4
                            : (int)0x80000000u;
@@ -170,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvBfArgs a) {
   }
 }
 
-template <int HIN, bool MASK>
+template <int HIN, bool MASK, int LAY = 0>
 int launch_conv_bf16(const ConvBfArgs& a, hipStream_t st) {
   using G = ConvBfGeom<HIN>;
   constexpr int lds = G::LDS_DWORDS * 4;
@@ -178,7 +222,7 @@ int launch_conv_bf16(const ConvBfArgs& a, hipStream_t st) {
   static bool attr_dev[kMaxDevices] = {};
   bool& attr = attr_dev[drq_device()];
   if (!attr) {
-    const hipError_t e = hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<HIN, MASK>,
+    const hipError_t e = hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<HIN, MASK, LAY>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     attr = true;
@@ -186,7 +230,7 @@ int launch_conv_bf16(const ConvBfArgs& a, hipStream_t st) {
   long blocks = (long)a.nb * NPART;
   const long cap = 2L * drq_num_cus();
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL((conv3x3_bf16_kernel<HIN, MASK>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv3x3_bf16_kernel<HIN, MASK, LAY>), dim3((unsigned)blocks), dim3(256), lds, st, a);
   DRQ_LAUNCH_CHECK();
   return DRQ_OK;
 }
@@ -222,7 +266,8 @@ struct WgradBfGeom {
   static constexpr int WAVE_DWORDS = 3 * 32 * XROW + 32 * DROW;
 };
 
-template <int HIN>
+// XNHWC: the layer input is bf16 [frame][y][x][32 channels] (see the head of the file)
+template <int HIN, bool XNHWC = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_bf16_kernel(WgradBfArgs a) {
   using G = WgradBfGeom<HIN>;
   constexpr int HOUT = G::HOUT, KB = G::KB, XROW = G::XROW, DROW = G::DROW;
@@ -275,16 +320,53 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_bf16_kernel(WgradBfArgs 
     }
   };
 
+  // the same from the channel-contiguous layout: item = (pixel pair, 16-byte piece of eight channels); the two
+  // pixels' values of a channel are packed into the dword the [channel][pixel pair] image wants (v_perm)
+  constexpr int XIT2 = (4 * XPAIRS + 63) / 64;
+  auto stage_x_nhwc = [&](const u32x4* xrow, int slot) {  // xrow: pixel 0 of that row (4 pieces per pixel)
+    u32x4 p0[XIT2], p1[XIT2];
+#pragma unroll
+    for (int k = 0; k < XIT2; ++k) {
+      int it = k * 64 + lane;
+      it = it < 4 * XPAIRS ? it : 4 * XPAIRS - 1;
+      const int pr = it >> 2, c4 = it & 3;
+      p0[k] = xrow[(2 * pr) * 4 + c4];
+      p1[k] = xrow[(2 * pr + 1 < HIN ? 2 * pr + 1 : 2 * pr) * 4 + c4];
+    }
+#pragma unroll
+    for (int k = 0; k < XIT2; ++k) {
+      const int it = k * 64 + lane;
+      if (it < 4 * XPAIRS) {
+        const int pr = it >> 2, c4 = it & 3;
+        const bool odd_ok = 2 * pr + 1 < HIN;
+        unsigned* dst = xs + (slot * 32 + 8 * c4) * XROW + pr;          // channels 8*c4 + j, j = 0..7
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned a0 = p0[k][e], a1 = odd_ok ? p1[k][e] : 0u;
+          const unsigned lo = __builtin_amdgcn_perm(a1, a0, 0x05040100u);   // (a0.lo16, a1.lo16)
+          const unsigned hi = __builtin_amdgcn_perm(a1, a0, 0x07060302u);   // (a0.hi16, a1.hi16)
+          dst[(2 * e) * XROW] = lo;
+          dst[(2 * e + 1) * XROW] = hi;
+        }
+      }
+    }
+  };
+
   int prev_b = -1, prev_oy = -2;
   for (int u = u0; u < u1; ++u) {
     const int b = u / HOUT, oy = u - b * HOUT;
     const float* xsrc = a.x + (long)b * 32 * HIN * HIN;
+    const u32x4* xsrc4 = reinterpret_cast<const u32x4*>(a.x) + (long)b * HIN * HIN * 4;
     // (single wave: its LDS operations complete in order, no barrier needed)
     if (b == prev_b && oy == prev_oy + 1) {
-      stage_x(xsrc + (long)(oy + 2) * HIN, (oy + 2) % 3);
+      if constexpr (XNHWC) stage_x_nhwc(xsrc4 + (long)(oy + 2) * HIN * 4, (oy + 2) % 3);
+      else stage_x(xsrc + (long)(oy + 2) * HIN, (oy + 2) % 3);
     } else {
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) stage_x(xsrc + (long)(oy + ky) * HIN, (oy + ky) % 3);
+      for (int ky = 0; ky < 3; ++ky) {
+        if constexpr (XNHWC) stage_x_nhwc(xsrc4 + (long)(oy + ky) * HIN * 4, (oy + ky) % 3);
+        else stage_x(xsrc + (long)(oy + ky) * HIN, (oy + ky) % 3);
+      }
     }
     prev_b = b; prev_oy = oy;
     {
@@ -356,7 +438,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_bf16_kernel(WgradBfArgs 
     out[i] = (red[i] + red[WG_PART + i]) + (red[2 * WG_PART + i] + red[3 * WG_PART + i]);
 }
 
-template <int HIN>
+template <int HIN, bool XNHWC = false>
 int launch_wgrad_bf16(const WgradBfArgs& a0, float* ws, size_t ws_bytes, int* nblocks_out, hipStream_t st) {
   using G = WgradBfGeom<HIN>;
   constexpr int lds_dwords = 4 * G::WAVE_DWORDS > 4 * WG_PART ? 4 * G::WAVE_DWORDS : 4 * WG_PART;
@@ -371,12 +453,12 @@ int launch_wgrad_bf16(const WgradBfArgs& a0, float* ws, size_t ws_bytes, int* nb
   static bool attr_dev[kMaxDevices] = {};
   bool& attr = attr_dev[drq_device()];
   if (!attr) {
-    const hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16_kernel<HIN>,
+    const hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16_kernel<HIN, XNHWC>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_dwords * 4);
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<HIN>), dim3((unsigned)blocks), dim3(256), lds_dwords * 4, st, a);
+  hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<HIN, XNHWC>), dim3((unsigned)blocks), dim3(256), lds_dwords * 4, st, a);
   DRQ_LAUNCH_CHECK();
   if (nblocks_out) *nblocks_out = (int)blocks;
   return DRQ_OK;
@@ -388,47 +470,100 @@ int launch_wgrad_bf16(const WgradBfArgs& a0, float* ws, size_t ws_bytes, int* nb
 int drq_conv3x3_wgrad_reduce_multi(int n, const float* const* part, const int* nblocks, const int* cin,
                                    float* const* dw, float* const* db, hipStream_t st);
 
-// ---- C ABI (include/drqv2_hip.h), argument meaning as the fp32 entries of conv.hip ------------------------------
-extern "C" {
-
-DRQ_API int drq_conv3x3_fwd_bf16(const float* x, const float* w, const float* bias, float* y, int nb, int hin, int relu, long y_bs,
-                         long y_cs, long y_rs, long y_off, hipStream_t st) {
-  if (!x || !w || !y || nb <= 0) return DRQ_EARG;
+// ---- internal (step.hip) and C ABI: the same launches with the bf16 channel-contiguous layout on some operands -----
+// x: bf16 [nb][hin][hin][32] when lay & 1, else fp32 NCHW; y: bf16 [nb][hout][hout][32] when lay & 2 (the strides are
+// ignored), else fp32 with the given strides
+int drq_conv3x3_fwd_bf16_lay(const void* x, const float* w, const float* bias, void* y, int nb, int hin, int relu,
+                             long y_bs, long y_cs, long y_rs, long y_off, int lay, hipStream_t st) {
+  if (!x || !w || !y || nb <= 0 || (lay & ~3)) return DRQ_EARG;
+  const int hout = hin - 2;
+  if (lay & 2) { y_bs = 16L * hout * hout; y_cs = 0; y_rs = 0; y_off = 0; }   // 64 bytes per pixel, in floats
   const size_t yb = (size_t)nb * y_bs * 4;
-  if (yb >= (1ull << 31) || y_off < 0 || y_bs <= 0) return DRQ_EARG;
-  ConvBfArgs a{x, w, bias, nullptr, y, y_bs, y_cs, y_rs, y_off, (unsigned)yb, 0u, nb, relu, 0};
-  if (hin == 41) return launch_conv_bf16<41, false>(a, st);
-  if (hin == 39) return launch_conv_bf16<39, false>(a, st);
-  if (hin == 37) return launch_conv_bf16<37, false>(a, st);
+  if (yb >= (1ull << 31) || y_off < 0 || y_bs <= 0 || ((uintptr_t)x & 15) || ((lay & 2) && ((uintptr_t)y & 15))) return DRQ_EARG;
+  ConvBfArgs a{(const float*)x, w, bias, nullptr, (float*)y, y_bs, y_cs, y_rs, y_off, (unsigned)yb, 0u, nb, relu, 0};
+#define DRQ_BF_FWD(H)                                            \
+  if (hin == H) {                                                \
+    if (lay == 0) return launch_conv_bf16<H, false, 0>(a, st);   \
+    if (lay == 1) return launch_conv_bf16<H, false, 1>(a, st);   \
+    if (lay == 2) return launch_conv_bf16<H, false, 2>(a, st);   \
+    return launch_conv_bf16<H, false, 3>(a, st);                 \
+  }
+  DRQ_BF_FWD(41) DRQ_BF_FWD(39) DRQ_BF_FWD(37)
+#undef DRQ_BF_FWD
   return DRQ_EARG;
 }
 
-DRQ_API int drq_conv3x3_dgrad_bf16(const float* dy_pad, const float* w, const float* mask, float* dx, int nb, int hout, long dx_bs,
-                           long dx_cs, long dx_rs, long dx_off, hipStream_t st) {
+// mask: bf16 [nb][hout+2][hout+2][32] when mask_nhwc, else fp32 NCHW
+int drq_conv3x3_dgrad_bf16_lay(const float* dy_pad, const float* w, const void* mask, float* dx, int nb, int hout,
+                               long dx_bs, long dx_cs, long dx_rs, long dx_off, int mask_nhwc, hipStream_t st) {
   if (!dy_pad || !w || !dx || !mask || nb <= 0) return DRQ_EARG;
   const int hp = hout + 4;
   const size_t yb = (size_t)nb * dx_bs * 4;
-  const size_t mb = (size_t)nb * 32 * (hout + 2) * (hout + 2) * 4;
-  if (yb >= (1ull << 31) || mb >= (1ull << 31) || dx_off < 0 || dx_bs <= 0) return DRQ_EARG;
-  ConvBfArgs a{dy_pad, w, nullptr, mask, dx, dx_bs, dx_cs, dx_rs, dx_off, (unsigned)yb, (unsigned)mb, nb, 0, 1};
+  const size_t mb = (size_t)nb * 32 * (hout + 2) * (hout + 2) * (mask_nhwc ? 2 : 4);
+  if (yb >= (1ull << 31) || mb >= (1ull << 31) || dx_off < 0 || dx_bs <= 0 || (mask_nhwc && ((uintptr_t)mask & 15))) return DRQ_EARG;
+  ConvBfArgs a{dy_pad, w, nullptr, (const float*)mask, dx, dx_bs, dx_cs, dx_rs, dx_off, (unsigned)yb, (unsigned)mb, nb, 0, 1};
+  if (mask_nhwc) {
+    if (hp == 39) return launch_conv_bf16<39, true, 4>(a, st);
+    if (hp == 41) return launch_conv_bf16<41, true, 4>(a, st);
+    if (hp == 43) return launch_conv_bf16<43, true, 4>(a, st);
+    return DRQ_EARG;
+  }
   if (hp == 39) return launch_conv_bf16<39, true>(a, st);
   if (hp == 41) return launch_conv_bf16<41, true>(a, st);
   if (hp == 43) return launch_conv_bf16<43, true>(a, st);
   return DRQ_EARG;
 }
 
+// ---- C ABI (include/drqv2_hip.h), argument meaning as the fp32 entries of conv.hip ------------------------------
+extern "C" {
+
+DRQ_API int drq_conv3x3_fwd_bf16_nhwc(const void* x, const float* w, const float* bias, void* y, int nb, int hin, int relu,
+                                      int x_nhwc, int y_nhwc, hipStream_t st) {
+  const int hout = hin - 2;
+  return drq_conv3x3_fwd_bf16_lay(x, w, bias, y, nb, hin, relu, 32L * hout * hout, (long)hout * hout, hout, 0,
+                                  (x_nhwc ? 1 : 0) | (y_nhwc ? 2 : 0), st);
+}
+
+DRQ_API int drq_conv3x3_dgrad_bf16_nhwc(const float* dy_pad, const float* w, const void* mask_nhwc, float* dx, int nb, int hout,
+                                        long dx_bs, long dx_cs, long dx_rs, long dx_off, hipStream_t st) {
+  return drq_conv3x3_dgrad_bf16_lay(dy_pad, w, mask_nhwc, dx, nb, hout, dx_bs, dx_cs, dx_rs, dx_off, 1, st);
+}
+
+DRQ_API int drq_conv3x3_fwd_bf16(const float* x, const float* w, const float* bias, float* y, int nb, int hin, int relu, long y_bs,
+                         long y_cs, long y_rs, long y_off, hipStream_t st) {
+  return drq_conv3x3_fwd_bf16_lay(x, w, bias, y, nb, hin, relu, y_bs, y_cs, y_rs, y_off, 0, st);
+}
+
+DRQ_API int drq_conv3x3_dgrad_bf16(const float* dy_pad, const float* w, const float* mask, float* dx, int nb, int hout, long dx_bs,
+                           long dx_cs, long dx_rs, long dx_off, hipStream_t st) {
+  return drq_conv3x3_dgrad_bf16_lay(dy_pad, w, mask, dx, nb, hout, dx_bs, dx_cs, dx_rs, dx_off, 0, st);
+}
+
 }  // extern "C"
 
 // internal (step.hip): partial records only; one reduction launch serves all layers
-int drq_conv3x3_wgrad_partial_bf16(const float* x, const float* dy, int nb, int hin, long dy_bs, long dy_cs, long dy_rs,
-                                   long dy_off, float* part, size_t part_bytes, int* nblocks, hipStream_t st) {
+// x_nhwc: x is bf16 [nb][hin][hin][32] instead of fp32 NCHW
+int drq_conv3x3_wgrad_partial_bf16_lay(const void* x, const float* dy, int nb, int hin, long dy_bs, long dy_cs, long dy_rs,
+                                       long dy_off, float* part, size_t part_bytes, int* nblocks, int x_nhwc,
+                                       hipStream_t st) {
   if (!x || !dy || !part || !nblocks || nb <= 0 || dy_off < 0 || dy_bs <= 0) return DRQ_EARG;
-  if (((size_t)part & 15) != 0) return DRQ_EARG;
-  WgradBfArgs a{x, dy, dy_bs, dy_cs, dy_rs, dy_off, nullptr, nb};
+  if (((size_t)part & 15) != 0 || (x_nhwc && ((uintptr_t)x & 15))) return DRQ_EARG;
+  WgradBfArgs a{(const float*)x, dy, dy_bs, dy_cs, dy_rs, dy_off, nullptr, nb};
+  if (x_nhwc) {
+    if (hin == 41) return launch_wgrad_bf16<41, true>(a, part, part_bytes, nblocks, st);
+    if (hin == 39) return launch_wgrad_bf16<39, true>(a, part, part_bytes, nblocks, st);
+    if (hin == 37) return launch_wgrad_bf16<37, true>(a, part, part_bytes, nblocks, st);
+    return DRQ_EARG;
+  }
   if (hin == 41) return launch_wgrad_bf16<41>(a, part, part_bytes, nblocks, st);
   if (hin == 39) return launch_wgrad_bf16<39>(a, part, part_bytes, nblocks, st);
   if (hin == 37) return launch_wgrad_bf16<37>(a, part, part_bytes, nblocks, st);
   return DRQ_EARG;
+}
+
+int drq_conv3x3_wgrad_partial_bf16(const float* x, const float* dy, int nb, int hin, long dy_bs, long dy_cs, long dy_rs,
+                                   long dy_off, float* part, size_t part_bytes, int* nblocks, hipStream_t st) {
+  return drq_conv3x3_wgrad_partial_bf16_lay(x, dy, nb, hin, dy_bs, dy_cs, dy_rs, dy_off, part, part_bytes, nblocks, 0, st);
 }
 
 extern "C" DRQ_API int drq_conv3x3_wgrad_bf16(const float* x, const float* dy, float* dw, float* db, int nb, int hin,
@@ -437,6 +572,19 @@ extern "C" DRQ_API int drq_conv3x3_wgrad_bf16(const float* x, const float* dy, f
   if (!dw || !db || !ws) return DRQ_EARG;
   int nblk = 0;
   const int rc = drq_conv3x3_wgrad_partial_bf16(x, dy, nb, hin, dy_bs, dy_cs, dy_rs, dy_off, ws, ws_bytes, &nblk, st);
+  if (rc != DRQ_OK) return rc;
+  const float* parts[1] = {ws};
+  const int cins[1] = {32};
+  float *dws[1] = {dw}, *dbs[1] = {db};
+  return drq_conv3x3_wgrad_reduce_multi(1, parts, &nblk, cins, dws, dbs, st);
+}
+
+extern "C" DRQ_API int drq_conv3x3_wgrad_bf16_nhwc(const void* x_nhwc, const float* dy, float* dw, float* db, int nb, int hin,
+                                                   long dy_bs, long dy_cs, long dy_rs, long dy_off, float* ws,
+                                                   size_t ws_bytes, hipStream_t st) {
+  if (!dw || !db || !ws) return DRQ_EARG;
+  int nblk = 0;
+  const int rc = drq_conv3x3_wgrad_partial_bf16_lay(x_nhwc, dy, nb, hin, dy_bs, dy_cs, dy_rs, dy_off, ws, ws_bytes, &nblk, 1, st);
   if (rc != DRQ_OK) return rc;
   const float* parts[1] = {ws};
   const int cins[1] = {32};

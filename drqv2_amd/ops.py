@@ -162,6 +162,57 @@ def conv3x3_wgrad(x, dy, stride, bf16=False, wino=False):
     return dw, db
 
 
+def to_nhwc_bf16(x):
+    """fp32 [n,32,h,w] -> the bf16 channel-contiguous layout of the bf16 update ([n,h,w,32], include/drqv2_hip.h)."""
+    return x.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()
+
+
+def from_nhwc_bf16(y):
+    """the inverse, as fp32 [n,32,h,w] (the bf16 values, exactly)."""
+    return y.to(torch.float32).permute(0, 3, 1, 2).contiguous()
+
+
+def conv3x3_fwd_bf16_nhwc(x, w, b, relu=True, y_nhwc=True):
+    """x: fp32 [nb,32,hin,hin] or bf16 [nb,hin,hin,32] (layout above) -> y in that layout (bf16) or fp32 NCHW."""
+    lib = _lib.load()
+    x_nhwc = x.dtype == torch.bfloat16
+    nb = x.shape[0]
+    hin = x.shape[1] if x_nhwc else x.shape[2]
+    hout = hin - 2
+    assert x.is_cuda and x.is_contiguous() and (x.shape[3] == 32 if x_nhwc else x.shape[1] == 32)
+    y = (torch.empty((nb, hout, hout, 32), device=x.device, dtype=torch.bfloat16) if y_nhwc else
+         torch.empty((nb, 32, hout, hout), device=x.device, dtype=torch.float32))
+    check(lib.drq_conv3x3_fwd_bf16_nhwc(ptr(x), ptr(w), ptr(b), ptr(y), nb, hin, int(relu), int(x_nhwc), int(y_nhwc),
+                                        _stream()), "drq_conv3x3_fwd_bf16_nhwc")
+    return y
+
+
+def conv3x3_dgrad_bf16_nhwc(dy_pad, w, mask_nhwc):
+    lib = _lib.load()
+    _need(dy_pad, name="dy_pad"), _need(w, name="w")
+    nb, _, hp, _ = dy_pad.shape
+    hout = hp - 4
+    hin = hout + 2
+    assert mask_nhwc.dtype == torch.bfloat16 and tuple(mask_nhwc.shape) == (nb, hin, hin, 32) and mask_nhwc.is_contiguous()
+    dx = torch.empty((nb, 32, hin, hin), device=dy_pad.device, dtype=torch.float32)
+    check(lib.drq_conv3x3_dgrad_bf16_nhwc(ptr(dy_pad), ptr(w), ptr(mask_nhwc), ptr(dx), nb, hout, 32 * hin * hin, hin * hin,
+                                          hin, 0, _stream()), "drq_conv3x3_dgrad_bf16_nhwc")
+    return dx
+
+
+def conv3x3_wgrad_bf16_nhwc(x_nhwc, dy):
+    lib = _lib.load()
+    nb, hin, _, _ = x_nhwc.shape
+    assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.is_contiguous() and x_nhwc.shape[3] == 32
+    dw = torch.empty((32, 32, 3, 3), device=dy.device, dtype=torch.float32)
+    db = torch.empty((32,), device=dy.device, dtype=torch.float32)
+    nbytes = lib.drq_conv3x3_wgrad_ws_bytes()
+    ws = torch.empty((nbytes // 4,), device=dy.device, dtype=torch.float32)
+    check(lib.drq_conv3x3_wgrad_bf16_nhwc(ptr(x_nhwc), dy.data_ptr(), ptr(dw), ptr(db), nb, hin, dy.stride(0), dy.stride(1),
+                                          dy.stride(2), 0, ptr(ws), nbytes, _stream()), "drq_conv3x3_wgrad_bf16_nhwc")
+    return dw, db
+
+
 def gemm(A, a_kc, B, b_kc, M, N, K, lda=None, ldb=None, bias=None, relu=False, aux=None, nbatch=1, a_bs=0,
          b_bs=0, c_bs=None, bias_bs=0, aux_bs=0, tile=0, splitk=0, out=None, ldc=None):
     lib = _lib.load()

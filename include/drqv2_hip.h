@@ -99,6 +99,17 @@ int drq_conv3x3_dgrad_bf16(const float* dy_pad, const float* w, const float* mas
                            long dx_bs, long dx_cs, long dx_rs, long dx_off, drq_stream_t stream);
 int drq_conv3x3_wgrad_bf16(const float* x, const float* dy, float* dw, float* db, int nb, int hin, long dy_bs,
                            long dy_cs, long dy_rs, long dy_off, float* ws, size_t ws_bytes, drq_stream_t stream);
+/* The same three launches with activations in the layout the bf16 update keeps between the encoder layers (round 3):
+ * bf16 [frame][y][x][32 channels], 64 bytes per pixel, 16-byte aligned.  A value stored in that layout is the bf16
+ * rounding the entries above apply when they stage it, in the same place of the same sums, so results are identical
+ * bit for bit.  fwd: x in that layout when x_nhwc (else fp32 NCHW), y in that layout when y_nhwc (else contiguous fp32
+ * NCHW); dgrad: the mask in that layout ([nb][hout+2][hout+2][32]); wgrad: x in that layout. */
+int drq_conv3x3_fwd_bf16_nhwc(const void* x, const float* w, const float* bias, void* y, int nb, int hin, int relu,
+                              int x_nhwc, int y_nhwc, drq_stream_t stream);
+int drq_conv3x3_dgrad_bf16_nhwc(const float* dy_pad, const float* w, const void* mask_nhwc, float* dx, int nb, int hout,
+                                long dx_bs, long dx_cs, long dx_rs, long dx_off, drq_stream_t stream);
+int drq_conv3x3_wgrad_bf16_nhwc(const void* x_nhwc, const float* dy, float* dw, float* db, int nb, int hin, long dy_bs,
+                                long dy_cs, long dy_rs, long dy_off, float* ws, size_t ws_bytes, drq_stream_t stream);
 
 /* ---- nn.Linear forward / backward (drqv2.py:74-81,100-111) as one strided, batched GEMM:
  *   C[b][m][n] = epi( sum_k A_b(m,k) * B_b(k,n) ),  epi(v) = relu?(v + bias[n]) * (aux[m][n] > 0)?

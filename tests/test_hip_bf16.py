@@ -56,6 +56,40 @@ def test_conv_bf16_fwd_dgrad_wgrad(ops, hin, nb):
     assert gerr(db, dy.double().sum((0, 2, 3))) <= 3e-6
 
 
+@pytest.mark.parametrize("hin,nb", [(41, 3), (39, 2), (37, 5), (41, 130)])
+def test_conv_bf16_channel_contiguous_layout_is_the_same_arithmetic(ops, hin, nb):
+    """The layout the bf16 update keeps between the encoder layers (bf16 [frame][y][x][32 channels]): a value stored in
+    it is the rounding the fp32-storage kernels apply when they stage the value, so forward (either side in either
+    layout), masked input gradient and weight gradient must equal the fp32-storage kernels BIT FOR BIT."""
+    g = torch.Generator(device="cuda").manual_seed(7 * hin + nb)
+    rn = lambda *sh: torch.randn(*sh, device="cuda", generator=g)
+    hout = hin - 2
+    x, w, b = rn(nb, 32, hin, hin), rn(32, 32, 3, 3) * 0.1, rn(32) * 0.1
+    xn = ops.to_nhwc_bf16(x)
+    assert torch.equal(ops.from_nhwc_bf16(xn), x.to(torch.bfloat16).float())          # the helpers invert each other
+    y = ops.conv3x3_fwd(x, w, b, 1, bf16=True)                                         # fp32 in, fp32 out
+    y_r = y.to(torch.bfloat16).float()
+    for x_in in (x, xn):
+        yo = ops.conv3x3_fwd_bf16_nhwc(x_in, w, b, relu=True, y_nhwc=False)
+        assert torch.equal(yo, y)
+        yn = ops.conv3x3_fwd_bf16_nhwc(x_in, w, b, relu=True, y_nhwc=True)
+        assert torch.equal(ops.from_nhwc_bf16(yn), y_r)
+    # without ReLU too (the sign of a rounded value is the value's)
+    y0 = ops.conv3x3_fwd(x, w, b, 1, relu=False, bf16=True)
+    assert torch.equal(ops.from_nhwc_bf16(ops.conv3x3_fwd_bf16_nhwc(xn, w, b, relu=False)), y0.to(torch.bfloat16).float())
+    # masked input gradient: the mask in the layout
+    dy = rn(nb, 32, hout, hout)
+    dy_pad = torch.zeros(nb, 32, hout + 4, hout + 4, device="cuda")
+    dy_pad[:, :, 2:-2, 2:-2] = dy
+    mask = torch.relu(rn(nb, 32, hin, hin))                                            # an activation: zeros and positives
+    dx = ops.conv3x3_dgrad(dy_pad, w, mask, bf16=True)
+    assert torch.equal(ops.conv3x3_dgrad_bf16_nhwc(dy_pad, w, ops.to_nhwc_bf16(mask)), dx)
+    # weight gradient: the layer input in the layout
+    dw, db = ops.conv3x3_wgrad(x, dy_pad[:, :, 2:-2, 2:-2], 1, bf16=True)
+    dwn, dbn = ops.conv3x3_wgrad_bf16_nhwc(xn, dy_pad[:, :, 2:-2, 2:-2])
+    assert torch.equal(dwn, dw) and torch.equal(dbn, db)
+
+
 @pytest.mark.parametrize("n", [2, 70])
 def test_fused_aug_conv1_bf16(ops, n):
     """The bf16-MFMA form of the fused aug + conv1 launch: the stored encoder input is the fp32 one bit for bit; the
