@@ -46,6 +46,7 @@ PROTOTYPES = {
     "drq_aug_fwd_f32": (I, [P, P, P, P, I, I, I, I, P]),
     "drq_conv1_aug_fwd": (I, [P, P, P, P, P, P, P, P, P, I, I, P]),
     "drq_conv1_aug_fwd_bf16": (I, [P, P, P, P, P, P, P, P, P, I, I, P]),
+    "drq_conv1_aug_fwd_bf16_nhwc": (I, [P, P, P, P, P, P, P, P, P, I, I, P]),
     "drq_conv1_aug_fwd_indexed": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, P]),
     "drq_conv3x3_fwd": (I, [P, P, P, P, I, I, I, I, I, L, L, L, L, P]),
     "drq_conv3x3_dgrad": (I, [P, P, P, P, I, I, L, L, L, L, P]),

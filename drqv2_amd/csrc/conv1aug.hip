@@ -73,6 +73,7 @@ struct Conv1AugArgs {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8_c1 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4_c1 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_c1 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned pack_bf16_c1(float lo, float hi) {      // RNE, lo in bits 15:0
   typedef __bf16 bf16x2_c1 __attribute__((ext_vector_type(2)));
@@ -94,7 +95,8 @@ __device__ __forceinline__ float div255(float v) {   // correctly rounded v / 25
 // operands rounded to bf16 as they are read from the fp32 LDS tile.  Stages 1 and 2 (and the stored encoder input)
 // are unchanged.  The bf16 matrix unit is separate from the f32 VALU datapath: here the two workgroups of a CU DO
 // overlap (one augments while the other multiplies).
-template <int ABL, bool BF = false>
+// YN (with BF): y is written as bf16 [frame][41][41][32 channels] (conv_bf16.hip's activation layout) instead of fp32 NCHW
+template <int ABL, bool BF = false, bool YN = false>
 __global__ __launch_bounds__(NTHR, 2 * NTHR / 256) void conv1_aug_kernel(Conv1AugArgs a) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -397,6 +399,18 @@ __global__ __launch_bounds__(NTHR, 2 * NTHR / 256) void conv1_aug_kernel(Conv1Au
       }
       }
       const int oy = done.r0 + oyl;
+      if constexpr (YN) {      // channels 8g + 4*half + 0..3 of the pixel: 8 bytes at 16g + 8*half
+        const int yo = p0 < npix ? (((done.f * HO + oy) * HO + ox) * 16 + half * 2) * 4 : (int)0x80000000u;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[4 * g4 + e] > 0.f ? acc[4 * g4 + e] : 0.f;
+          const u32x2_c1 o = {pack_bf16_c1(v[0], v[1]), pack_bf16_c1(v[2], v[3])};
+          __builtin_amdgcn_raw_buffer_store_b64(o, yrsrc, yo, g4 * 16, 0);
+        }
+        continue;
+      }
       const int yoff = p0 < npix ? (((done.f * 32 + 4 * half) * HO + oy) * HO + ox) * 4 : (int)0x80000000u;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -423,7 +437,8 @@ extern "C" DRQ_API void drq_dev_conv1aug_stamps(void* p) { g_conv1aug_stamps = (
 
 // C ABI (include/drqv2_hip.h): both views of the update through aug + conv1 in one launch.
 //   y [2n][32][41][41] = relu(conv1(aug(view)/255 - 0.5));  xaug [2n][9][84][84]: frames [0, n_store) are written.
-// bf_mma != 0: the layer's products on the bf16 MFMA (the bf16 update path; internal and drq_conv1_aug_fwd_bf16)
+// bf_mma != 0: the layer's products on the bf16 MFMA (the bf16 update path; internal and drq_conv1_aug_fwd_bf16);
+// bf_mma == 2: y is bf16 [2n][41][41][32] (drq_conv1_aug_fwd_bf16_nhwc)
 int drq_conv1_aug_fwd_any(int bf_mma, const uint8_t* obs, const float* shift, const uint8_t* obs1, const float* shift1,
                           const float* base_grid, const float* w, const float* bias, float* xaug, float* y, int n,
                           int n_store, hipStream_t st, const float* const* wino_w, float* wino_u, const long* fidx0,
@@ -432,8 +447,8 @@ int drq_conv1_aug_fwd_any(int bf_mma, const uint8_t* obs, const float* shift, co
     return DRQ_EARG;
   if (n_store > 0 && !xaug) return DRQ_EARG;
   if (((uintptr_t)obs & 3) || ((uintptr_t)obs1 & 3)) return DRQ_EARG;     // rows are read as dwords
-  const size_t yb = (size_t)2 * n * 32 * PO * 4;
-  if (yb >= (1ull << 31)) return DRQ_EARG;
+  const size_t yb = (size_t)2 * n * 32 * PO * (bf_mma == 2 ? 2 : 4);      // 2: bf16 [2n][41][41][32]
+  if (yb >= (1ull << 31) || (bf_mma == 2 && ((uintptr_t)y & 15))) return DRQ_EARG;
   Conv1AugArgs a{};
   a.obs[0] = obs; a.obs[1] = obs1;
   a.fidx[0] = fidx0; a.fidx[1] = fidx1;
@@ -456,6 +471,9 @@ int drq_conv1_aug_fwd_any(int bf_mma, const uint8_t* obs, const float* shift, co
                                        LDS_BYTES);
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void*)conv1_aug_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)conv1_aug_kernel<0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              LDS_BYTES);
 #ifdef DRQ_DEV
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv1_aug_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv1_aug_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -484,7 +502,8 @@ int drq_conv1_aug_fwd_any(int bf_mma, const uint8_t* obs, const float* shift, co
     }
   }
   if (bf_mma) {
-    hipLaunchKernelGGL((conv1_aug_kernel<0, true>), dim3((unsigned)blocks), dim3(NTHR), LDS_BYTES, st, a);
+    if (bf_mma == 2) hipLaunchKernelGGL((conv1_aug_kernel<0, true, true>), dim3((unsigned)blocks), dim3(NTHR), LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((conv1_aug_kernel<0, true>), dim3((unsigned)blocks), dim3(NTHR), LDS_BYTES, st, a);
     DRQ_LAUNCH_CHECK();
     return DRQ_OK;
   }
@@ -497,7 +516,8 @@ int drq_conv1_aug_fwd_any(int bf_mma, const uint8_t* obs, const float* shift, co
     default: hipLaunchKernelGGL(conv1_aug_kernel<0>, dim3((unsigned)blocks), dim3(NTHR), LDS_BYTES, st, a);
   }
 #else
-  if (bf_mma) hipLaunchKernelGGL((conv1_aug_kernel<0, true>), dim3((unsigned)blocks), dim3(NTHR), LDS_BYTES, st, a);
+  if (bf_mma == 2) hipLaunchKernelGGL((conv1_aug_kernel<0, true, true>), dim3((unsigned)blocks), dim3(NTHR), LDS_BYTES, st, a);
+  else if (bf_mma) hipLaunchKernelGGL((conv1_aug_kernel<0, true>), dim3((unsigned)blocks), dim3(NTHR), LDS_BYTES, st, a);
   else hipLaunchKernelGGL(conv1_aug_kernel<0>, dim3((unsigned)blocks), dim3(NTHR), LDS_BYTES, st, a);
 #endif
   DRQ_LAUNCH_CHECK();
@@ -526,6 +546,13 @@ DRQ_API int drq_conv1_aug_fwd_bf16(const uint8_t* obs, const float* shift, const
                                    int n, int n_store, hipStream_t st) {
   return drq_conv1_aug_fwd_any(1, obs, shift, obs1, shift1, base_grid, w, bias, xaug, y, n, n_store, st, nullptr, nullptr,
                                nullptr, nullptr);
+}
+
+DRQ_API int drq_conv1_aug_fwd_bf16_nhwc(const uint8_t* obs, const float* shift, const uint8_t* obs1, const float* shift1,
+                                        const float* base_grid, const float* w, const float* bias, float* xaug,
+                                        void* y_nhwc, int n, int n_store, hipStream_t st) {
+  return drq_conv1_aug_fwd_any(2, obs, shift, obs1, shift1, base_grid, w, bias, xaug, (float*)y_nhwc, n, n_store, st,
+                               nullptr, nullptr, nullptr, nullptr);
 }
 
 }  // extern "C"

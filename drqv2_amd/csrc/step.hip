@@ -85,7 +85,14 @@ int drq_polout_l1_fwd(const float* p2, const float* w3, const float* b3, float* 
                       int F, float std, float clip, int use_clip, const float* noise_hi, float* mu_hi, float* ha_hi,
                       long lda_hi, const float* noise_lo, float* mu_lo, float* ha_lo, long lda_lo, int nheads,
                       const float* const* w, const float* const* b, float* const* y, hipStream_t st);
-// conv_bf16.hip (internal)
+// conv_bf16.hip (internal): the bf16 launches with activations in bf16 [frame][y][x][32] where the flags say so
+int drq_conv3x3_fwd_bf16_lay(const void* x, const float* w, const float* bias, void* y, int nb, int hin, int relu,
+                             long y_bs, long y_cs, long y_rs, long y_off, int lay, hipStream_t st);
+int drq_conv3x3_dgrad_bf16_lay(const float* dy_pad, const float* w, const void* mask, float* dx, int nb, int hout,
+                               long dx_bs, long dx_cs, long dx_rs, long dx_off, int mask_nhwc, hipStream_t st);
+int drq_conv3x3_wgrad_partial_bf16_lay(const void* x, const float* dy, int nb, int hin, long dy_bs, long dy_cs, long dy_rs,
+                                       long dy_off, float* part, size_t part_bytes, int* nblocks, int x_nhwc,
+                                       hipStream_t st);
 int drq_conv3x3_wgrad_partial_bf16(const float* x, const float* dy, int nb, int hin, long dy_bs, long dy_cs, long dy_rs,
                                    long dy_off, float* part, size_t part_bytes, int* nblocks, hipStream_t st);
 // conv.hip (internal)
@@ -291,6 +298,9 @@ struct Ctx {
   float* p(long off) const { return s->params + off; }
   float* g(long off) const { return s->grads + off; }
   int bf16() const { return s->bf16 ? 1 : 0; }
+  // bf16 update: the outputs of conv1..conv3 (ACT1..3) are bf16 [frame][y][x][32] (conv_bf16.hip); the features (ACT4),
+  // the gradients and the encoder input stay fp32
+  bool acts16() const { return s->bf16 && !(s->flags & DRQ_STEP_BF16_FP32_ACTS); }
   float* gemm_ws() const { return ws(W_GEMM_WS); }
   size_t gemm_ws_bytes() const { return (size_t)16 * 1024 * 1024 * sizeof(float); }
 
@@ -367,8 +377,8 @@ int encoder_forward(const Ctx& c, const float* x, int nb, float* a1, float* a2, 
     const int hin = kEncH[l], hout = kEncH[l + 1];
     if (ev && l == 1 && hipEventRecord((hipEvent_t)ev[0], c.st) != hipSuccess) return DRQ_EARG;
     if (c.bf16() && l > 0)
-      CK(drq_conv3x3_fwd_bf16(in, c.p(P.enc_w[l]), c.p(P.enc_b[l]), outs[l], nb, hin, 1, 32L * hout * hout,
-                              (long)hout * hout, hout, 0, c.st));
+      CK(drq_conv3x3_fwd_bf16_lay(in, c.p(P.enc_w[l]), c.p(P.enc_b[l]), outs[l], nb, hin, 1, 32L * hout * hout,
+                                  (long)hout * hout, hout, 0, (x == nullptr && c.acts16()) ? (l < 3 ? 3 : 1) : 0, c.st));
     else if (l > 0)   // the 32->32 layers in Winograd F(2x2,3x3) form (conv_wino.hip); in the update (x == nullptr) the
                       // weight images come from the riders of the fused aug+conv1 launch
       CK(drq_conv3x3_fwd_wino_pre(in, c.p(P.enc_w[l]), x ? nullptr : c.ws(W_WINO_U) + (2L * (l - 1)) * 16384,
@@ -454,7 +464,7 @@ int phase_encode(const Ctx& c) {
   (void)C;
   // riders of the same launch: the Winograd images of the conv2..4 weights for this update's forward and backward
   const float* wino_w[3] = {c.p(c.P.enc_w[1]), c.p(c.P.enc_w[2]), c.p(c.P.enc_w[3])};
-  CK(drq_conv1_aug_fwd_any(c.bf16(), s->obs, s->shift_obs, s->next_obs, s->shift_next, s->base_grid,
+  CK(drq_conv1_aug_fwd_any(c.acts16() ? 2 : c.bf16(), s->obs, s->shift_obs, s->next_obs, s->shift_next, s->base_grid,
                            c.p(c.P.enc_w[0]), c.p(c.P.enc_b[0]), aug, c.ws(W_ACT1), B, s->store_aug_next ? 2 * B : B, st,
                            c.bf16() ? nullptr : wino_w, c.bf16() ? nullptr : c.ws(W_WINO_U), s->obs_index,
                            s->next_obs_index));
@@ -638,8 +648,8 @@ int phase_conv_backward(const Ctx& c) {
     parts[l] = part; cins[l] = l == 0 ? C : 32; dws[l] = c.g(P.enc_w[l]); dbs[l] = c.g(P.enc_b[l]);
     if (!merged) {
       if (l > 0)
-        CK(drq_conv3x3_wgrad_partial_bf16(c.ws(actid[l]), dy, B, hin, 32L * hp * hp, (long)hp * hp, hp, 2L * hp + 2, part,
-                                          quarter, &nblk[l], st));
+        CK(drq_conv3x3_wgrad_partial_bf16_lay(c.ws(actid[l]), dy, B, hin, 32L * hp * hp, (long)hp * hp, hp, 2L * hp + 2,
+                                              part, quarter, &nblk[l], c.acts16() ? 1 : 0, st));
       else
         CK(drq_conv3x3_wgrad_partial(c.ws(actid[l]), dy, B, C, hin, 2, 32L * hp * hp, (long)hp * hp, hp, 2L * hp + 2,
                                      part, quarter, &nblk[l], st));
@@ -649,8 +659,8 @@ int phase_conv_backward(const Ctx& c) {
       void* const* ev = s->timing_n >= 4 ? s->timing_events : nullptr;
       if (ev && l == 2 && hipEventRecord((hipEvent_t)ev[2], st) != hipSuccess) return DRQ_EARG;
       if (c.bf16())
-        CK(drq_conv3x3_dgrad_bf16(dy, c.p(P.enc_w[l]), c.ws(actid[l]), c.ws(dyid[l - 1]), B, hout, 32L * hpi * hpi,
-                                  (long)hpi * hpi, hpi, 2L * hpi + 2, st));
+        CK(drq_conv3x3_dgrad_bf16_lay(dy, c.p(P.enc_w[l]), c.ws(actid[l]), c.ws(dyid[l - 1]), B, hout, 32L * hpi * hpi,
+                                      (long)hpi * hpi, hpi, 2L * hpi + 2, c.acts16() ? 1 : 0, st));
       else
       CK(drq_conv3x3_dgrad_wino_pre(dy, c.p(P.enc_w[l]), c.ws(W_WINO_U) + (2L * (l - 1) + 1) * 16384, c.ws(actid[l]),
                                     c.ws(dyid[l - 1]), B, hout, 32L * hpi * hpi, (long)hpi * hpi, hpi, 2L * hpi + 2, st));

@@ -52,9 +52,10 @@ def random_shifts_aug(x, shift, pad=4, base=None, fuse_norm=False):
     return out
 
 
-def conv1_aug_fwd(obs, shift, obs1, shift1, w, b, n_store=None, base=None, bf16=False):
+def conv1_aug_fwd(obs, shift, obs1, shift1, w, b, n_store=None, base=None, bf16=False, y_nhwc=False):
     """Fused RandomShiftsAug + /255-0.5 + conv1 + ReLU on both views (drq_conv1_aug_fwd).
-    Returns (y [2n,32,41,41], xaug [2n,9,84,84] with frames [0,n_store) written, the rest zero)."""
+    Returns (y [2n,32,41,41], xaug [2n,9,84,84] with frames [0,n_store) written, the rest zero); y_nhwc (with bf16): y
+    is bf16 [2n,41,41,32] (drq_conv1_aug_fwd_bf16_nhwc)."""
     lib = _lib.load()
     n = obs.shape[0]
     _need(obs, torch.uint8, "obs")
@@ -64,9 +65,12 @@ def conv1_aug_fwd(obs, shift, obs1, shift1, w, b, n_store=None, base=None, bf16=
     shift, shift1 = _need(shift.reshape(n, 2), name="shift"), _need(shift1.reshape(n, 2), name="shift1")
     base = aug_base_grid(84, 4, obs.device) if base is None else _need(base, name="base")
     n_store = n if n_store is None else n_store
-    y = torch.empty((2 * n, 32, 41, 41), device=obs.device, dtype=torch.float32)
+    y = (torch.empty((2 * n, 41, 41, 32), device=obs.device, dtype=torch.bfloat16) if y_nhwc else
+         torch.empty((2 * n, 32, 41, 41), device=obs.device, dtype=torch.float32))
     xaug = torch.zeros((2 * n, 9, 84, 84), device=obs.device, dtype=torch.float32)
-    fn = lib.drq_conv1_aug_fwd_bf16 if bf16 else lib.drq_conv1_aug_fwd
+    if y_nhwc and not bf16:
+        raise _lib.DrqError("conv1_aug_fwd: the channel-contiguous bf16 output belongs to the bf16 form")
+    fn = lib.drq_conv1_aug_fwd_bf16_nhwc if y_nhwc else lib.drq_conv1_aug_fwd_bf16 if bf16 else lib.drq_conv1_aug_fwd
     check(fn(ptr(obs), ptr(shift), ptr(obs1), ptr(shift1), ptr(base), ptr(_need(w, name="w")), ptr(_need(b, name="b")),
              ptr(xaug), ptr(y), n, n_store, _stream()), "drq_conv1_aug_fwd")
     return y, xaug

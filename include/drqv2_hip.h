@@ -60,6 +60,11 @@ int drq_conv1_aug_fwd_indexed(const uint8_t* frames, const int64_t* idx, const f
 int drq_conv1_aug_fwd_bf16(const uint8_t* obs, const float* shift, const uint8_t* obs1, const float* shift1,
                            const float* base_grid, const float* w, const float* bias, float* xaug, float* y, int n,
                            int n_store, drq_stream_t stream);
+/* the same with y in the bf16 [2n][41][41][32 channels] layout of the bf16 update (see drq_conv3x3_fwd_bf16_nhwc):
+ * the values of drq_conv1_aug_fwd_bf16's y, rounded to bf16 */
+int drq_conv1_aug_fwd_bf16_nhwc(const uint8_t* obs, const float* shift, const uint8_t* obs1, const float* shift1,
+                                const float* base_grid, const float* w, const float* bias, float* xaug, void* y_nhwc,
+                                int n, int n_store, drq_stream_t stream);
 
 /* ---- Encoder conv layers (drqv2.py:55-59): Conv2d(cin,32,3,stride)+ReLU, 32 output channels.
  * Supported (cin,hin,stride): (9,84,2) (32,41,1) (32,39,1) (32,37,1).  y element (b,co,oy,ox) is
@@ -328,10 +333,14 @@ typedef struct {
                               * DRQ_STEP_NO_ROW_FUSION (1): LayerNorm / policy output layer / first MLP layers as separate
                               * launches (the round-2 schedule) instead of csrc/rowblock.hip's fused ones;
                               * DRQ_STEP_NO_GEMM3 (2): hidden-layer gradients on the round-2 kernels instead of
-                              * csrc/gemm3.hip.  0 = the production schedule. */
+                              * csrc/gemm3.hip;
+                              * DRQ_STEP_BF16_FP32_ACTS (4, bf16 only): the outputs of conv1..conv3 stay fp32 NCHW between
+                              * the layers (round 2's storage) instead of bf16 [frame][y][x][32] -- the same update bit
+                              * for bit, more memory traffic.  0 = the production schedule. */
 } DrqStep;
 #define DRQ_STEP_NO_ROW_FUSION 1
 #define DRQ_STEP_NO_GEMM3 2
+#define DRQ_STEP_BF16_FP32_ACTS 4
 
 /* Parameter arena: tensors in parameters() order of encoder, critic, actor, critic_target, each start
  * aligned to 64 floats, each network's segment padded to a multiple of 512 floats (a segment is one optimiser

@@ -108,6 +108,10 @@ def test_fused_aug_conv1_bf16(ops, n):
     ref_r = torch.relu(Fn.conv2d(r16(xaug32), r16(w), b.double(), stride=2))
     assert gerr(y, ref_r) <= 1e-5, gerr(y, ref_r)
     assert gerr(y, y32.double()) <= 2e-2
+    # the same launch writing its output in the bf16 [frame][y][x][32] layout: y rounded, nothing else
+    yn, xaug_n = ops.conv1_aug_fwd(obs, sh, obs1, sh1, w, b, n_store=2 * n, bf16=True, y_nhwc=True)
+    assert torch.equal(xaug_n, xaug)
+    assert torch.equal(ops.from_nhwc_bf16(yn), y.to(torch.bfloat16).float())
 
 
 def rnd(*shape, seed=0, scale=1.0):
@@ -227,6 +231,27 @@ def test_bf16_update_against_fp64_oracle(name):
     m2, _, _ = run_hip(ag, cfg, 1)
     assert all(v == v and abs(v) < 1e6 for v in m2.values())
     assert bool(torch.isfinite(ag._engine.params).all())
+
+
+@pytest.mark.parametrize("name", ["cheetah_b64", "humanoid_b32", "cheetah_b256"])
+def test_bf16_update_activation_storage_does_not_change_the_update(name):
+    """The bf16 update keeps the outputs of conv1..conv3 as bf16 [frame][y][x][32]; DRQ_STEP_BF16_FP32_ACTS keeps them
+    fp32 NCHW (round 2's storage, rounded when staged).  Same operands in the same sums: two updates from the same
+    state must leave the same parameters, Adam moments and metrics bit for bit."""
+    from tests.test_hip_step import WIDE, make_agent, run_hip
+    cfg = WIDE[name]
+    outs = []
+    for flags in (0, 4):
+        ag = make_agent(cfg).set_compute_dtype("bf16")
+        ag._engine.step_flags = flags
+        ms = [run_hip(ag, cfg, u)[0] for u in range(2)]
+        torch.cuda.synchronize()
+        eng = ag._engine
+        outs.append((ms, eng.params.clone(), eng.adam_m.clone(), eng.adam_v.clone(), eng.grads.clone()))
+    (m0, *a0), (m1, *a1) = outs
+    assert m0 == m1
+    for x, y in zip(a0, a1):
+        assert torch.equal(x, y)
 
 
 def test_config5_shape_humanoid_batch_2048_fp32_and_bf16():
