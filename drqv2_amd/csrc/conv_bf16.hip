@@ -8,7 +8,7 @@
 // equals an fp32-accumulated convolution of the bf16-rounded operands -- that is what tests/test_hip_bf16.py checks
 // (against fp64 on rounded operands: ~1e-6), next to the distance from the unrounded fp32 result (~3e-3).
 //
-// Forward / dgrad (conv3x3_bf16_kernel): a workgroup owns one (sample, third of the output rows).  It stages the
+// Forward / dgrad (conv3x3_bf16_kernel): a workgroup owns one (sample, third or quarter of the output rows).  It stages the
 // input rows of that third for all 32 channels into LDS as bf16 in [pixel][channel] order (80-byte pixel pitch: the
 // 16-byte operand reads of 16 neighbouring pixels fall on 64 distinct banks), so that the B operand of one MFMA --
 // 8 consecutive channels of one tap of one pixel -- is ONE aligned ds_read_b128.  The A operands (18 fragments: 9 taps
@@ -57,22 +57,27 @@ struct ConvBfArgs {
   int wmode;           // 0 forward, 1 dgrad (transposed + flipped weights)
 };
 
-constexpr int NPART = 3;
+// A workgroup's unit is load -> barrier -> MFMAs -> stores, one after the other; the workgroups of a CU hide each
+// other's phases.  With the bf16 channel-contiguous input (ten 16-byte loads per thread) three per CU measure 12 %
+// faster than two; with fp32 input (77 dword loads per thread in flight, 162 registers) three are 9 % slower.
+constexpr int conv_bf_wgs(int lay) { return (lay & 1) ? 3 : 2; }
 constexpr int PIXP = 20;   // dwords per pixel in LDS: 16 (32 bf16 channels) + 4 pad
 
-template <int HIN>
+template <int HIN, int LAY = 0>
 struct ConvBfGeom {
   static constexpr int HOUT = HIN - 2;
+  static constexpr int WGS = conv_bf_wgs(LAY);
+  static constexpr int NPART = (WGS == 3 && HIN >= 43) ? 4 : 3;   // parts per sample: WGS images fit a CU's 160 KB of LDS
   static constexpr int RP = (HOUT + NPART - 1) / NPART;           // output rows per part
   static constexpr int NIN = (RP + 2) * HIN;                      // staged pixels per part
   static constexpr int LDS_DWORDS = NIN * PIXP > 18 * 64 * 4 ? NIN * PIXP : 18 * 64 * 4;
 };
 
 template <int HIN, bool MASK, int LAY = 0>
-__global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvBfArgs a) {
+__global__ __launch_bounds__(256, conv_bf_wgs(LAY)) void conv3x3_bf16_kernel(ConvBfArgs a) {
   constexpr bool IN_NHWC = (LAY & 1) != 0, OUT_NHWC = (LAY & 2) != 0, MASK_NHWC = (LAY & 4) != 0;
-  using G = ConvBfGeom<HIN>;
-  constexpr int HOUT = G::HOUT, RP = G::RP, P = HOUT * HOUT;
+  using G = ConvBfGeom<HIN, LAY>;
+  constexpr int HOUT = G::HOUT, RP = G::RP, P = HOUT * HOUT, NPART = G::NPART;
   extern __shared__ __attribute__((aligned(16))) unsigned smem_u[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
@@ -216,9 +221,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(ConvBfArgs a) {
 
 template <int HIN, bool MASK, int LAY = 0>
 int launch_conv_bf16(const ConvBfArgs& a, hipStream_t st) {
-  using G = ConvBfGeom<HIN>;
+  using G = ConvBfGeom<HIN, LAY>;
   constexpr int lds = G::LDS_DWORDS * 4;
-  static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+  static_assert(G::WGS * lds <= 160 * 1024, "workgroups per CU");
   static bool attr_dev[kMaxDevices] = {};
   bool& attr = attr_dev[drq_device()];
   if (!attr) {
@@ -227,8 +232,8 @@ int launch_conv_bf16(const ConvBfArgs& a, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  long blocks = (long)a.nb * NPART;
-  const long cap = 2L * drq_num_cus();
+  long blocks = (long)a.nb * G::NPART;
+  const long cap = (long)G::WGS * drq_num_cus();
   if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL((conv3x3_bf16_kernel<HIN, MASK, LAY>), dim3((unsigned)blocks), dim3(256), lds, st, a);
   DRQ_LAUNCH_CHECK();
