@@ -59,8 +59,8 @@ PROTOTYPES = {
     "drq_conv3x3_dgrad_bf16": (I, [P, P, P, P, I, I, L, L, L, L, P]),
     "drq_conv3x3_wgrad_bf16": (I, [P, P, P, P, I, I, L, L, L, L, P, SZ, P]),
     "drq_conv3x3_fwd_bf16_nhwc": (I, [P, P, P, P, I, I, I, I, I, P]),
-    "drq_conv3x3_dgrad_bf16_nhwc": (I, [P, P, P, P, I, I, L, L, L, L, P]),
-    "drq_conv3x3_wgrad_bf16_nhwc": (I, [P, P, P, P, I, I, L, L, L, L, P, SZ, P]),
+    "drq_conv3x3_dgrad_bf16_nhwc": (I, [P, P, P, P, I, I, I, I, L, L, L, L, P]),
+    "drq_conv3x3_wgrad_bf16_nhwc": (I, [P, P, P, P, I, I, I, L, L, L, L, P, SZ, P]),
     "drq_gemm_f32": (I, [P, L, I, P, L, I, P, L, I, I, I, I, L, L, L, P, L, I, P, I, L, I, I, I, P, SZ, P]),
     "drq_gemm_batched_f32": (I, [I, P, L, I, P, L, I, P, L, I, I, I, P, I, P, I, P, I, I, I, P, SZ, P]),
     "drq_gemm_batched_bf16": (I, [I, P, L, I, P, L, I, P, L, I, I, I, P, I, P, I, P, I, I, P, SZ, P]),

@@ -55,6 +55,7 @@ struct ConvBfArgs {
   int nb;
   int relu;
   int wmode;           // 0 forward, 1 dgrad (transposed + flipped weights)
+  int y_pad;           // LAY & 2: the output is the interior of a [NB][HOUT+2*y_pad]^2[32] buffer (zero border kept by the caller)
 };
 
 // A workgroup's unit is load -> barrier -> MFMAs -> stores, one after the other; the workgroups of a CU hide each
@@ -190,7 +191,8 @@ __global__ __launch_bounds__(256, conv_bf_wgs(LAY)) void conv3x3_bf16_kernel(Con
         }
       }
       if constexpr (OUT_NHWC) {                // channels 8g + 4*half + 0..3: 8 bytes at 16g + 8*half of the pixel
-        const int yoff = p0 < npix ? ((b * P + oy * HOUT + ox) * 16 + half * 2) * 4 : (int)0x80000000u;
+        const int hp = HOUT + 2 * a.y_pad;
+        const int yoff = p0 < npix ? (((b * hp + oy + a.y_pad) * hp + ox + a.y_pad) * 16 + half * 2) * 4 : (int)0x80000000u;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           float v[4];
@@ -271,8 +273,10 @@ struct WgradBfGeom {
   static constexpr int WAVE_DWORDS = 3 * 32 * XROW + 32 * DROW;
 };
 
-// XNHWC: the layer input is bf16 [frame][y][x][32 channels] (see the head of the file)
-template <int HIN, bool XNHWC = false>
+// XNHWC: the layer input is bf16 [frame][y][x][32 channels] (see the head of the file); DYNHWC: dy is the bf16
+// [frame][HOUT+4][HOUT+4][32] buffer zero-padded by 2 that the input-gradient launches write (a.dy = its base; the
+// strides are not used).  The bias gradient then sums the bf16 values (with fp32 dy it sums the unrounded ones).
+template <int HIN, bool XNHWC = false, bool DYNHWC = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_bf16_kernel(WgradBfArgs a) {
   using G = WgradBfGeom<HIN>;
   constexpr int HOUT = G::HOUT, KB = G::KB, XROW = G::XROW, DROW = G::DROW;
@@ -293,6 +297,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_bf16_kernel(WgradBfArgs 
   float bs[DIT];                                       // bias gradient: this lane's pieces of the dY rows it staged
 #pragma unroll
   for (int k = 0; k < DIT; ++k) bs[k] = 0.f;
+  constexpr int DITN = DYNHWC ? (4 * DPAIRS + 63) / 64 : 1;
+  float bsn[DITN][8];                                  // DYNHWC: item (pixel pair, piece c4) -> channels 8*c4 + j
+#pragma unroll
+  for (int k = 0; k < DITN; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bsn[k][j] = 0.f;
 
   // (sample, output row) units split evenly over the waves of the grid; a wave walks its run in order, so
   // consecutive units of one sample share two of their three input rows: only row oy+2 is new
@@ -374,7 +384,38 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_bf16_kernel(WgradBfArgs 
       }
     }
     prev_b = b; prev_oy = oy;
-    {
+    if constexpr (DYNHWC) {
+      // item = (pixel pair, 16-byte piece of eight channels), as for x; DIT2 * 64 >= 4 * DPAIRS items
+      constexpr int HP = HOUT + 4;
+      constexpr int DIT2 = (4 * DPAIRS + 63) / 64;
+      static_assert(DIT2 <= DIT, "bias pieces");
+      const u32x4* drow = reinterpret_cast<const u32x4*>(a.dy) + (((long)b * HP + oy + 2) * HP + 2) * 4;
+      u32x4 p0[DIT2], p1[DIT2];
+#pragma unroll
+      for (int k = 0; k < DIT2; ++k) {
+        int it = k * 64 + lane;
+        it = it < 4 * DPAIRS ? it : 4 * DPAIRS - 1;
+        const int pr = it >> 2, c4 = it & 3;
+        p0[k] = drow[(2 * pr) * 4 + c4];
+        p1[k] = drow[(2 * pr + 1) * 4 + c4];          // pixel HOUT of the last pair is the zero border
+      }
+#pragma unroll
+      for (int k = 0; k < DIT2; ++k) {
+        const int it = k * 64 + lane;
+        if (it < 4 * DPAIRS) {
+          const int pr = it >> 2, c4 = it & 3;
+          unsigned* dst = ds + (8 * c4) * DROW + pr;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned a0 = p0[k][e], a1 = p1[k][e];
+            dst[(2 * e) * DROW] = __builtin_amdgcn_perm(a1, a0, 0x05040100u);
+            dst[(2 * e + 1) * DROW] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
+            bsn[k][2 * e] += __uint_as_float(a0 << 16) + __uint_as_float(a1 << 16);
+            bsn[k][2 * e + 1] += __uint_as_float(a0 & 0xffff0000u) + __uint_as_float(a1 & 0xffff0000u);
+          }
+        }
+      }
+    } else {
       const float* dsrc = a.dy + a.dy_off + (long)b * a.dy_bs + (long)oy * a.dy_rs;
       float v0[DIT], v1[DIT];
 #pragma unroll
@@ -420,11 +461,23 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_bf16_kernel(WgradBfArgs 
   // ---- bias gradient of this wave: lane pieces -> per-channel sums through the (now idle) wave-private LDS.
   // Item k*64+lane belongs to channel (k*64+lane)/DPAIRS; fixed order: deterministic.
   float* fl = reinterpret_cast<float*>(xs);
-#pragma unroll
-  for (int k = 0; k < DIT; ++k) fl[k * 64 + lane] = bs[k];
   float bsum = 0.f;
-  if (lane < 32) {
-    for (int pr = 0; pr < DPAIRS; ++pr) bsum += fl[lane * DPAIRS + pr];
+  if constexpr (DYNHWC) {
+#pragma unroll
+    for (int k = 0; k < DITN; ++k)
+      if (k * 64 + lane < 4 * DPAIRS) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fl[(k * 64 + lane) * 8 + j] = bsn[k][j];
+      }
+    if (lane < 32) {
+      for (int pr = 0; pr < DPAIRS; ++pr) bsum += fl[(pr * 4 + (lane >> 3)) * 8 + (lane & 7)];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < DIT; ++k) fl[k * 64 + lane] = bs[k];
+    if (lane < 32) {
+      for (int pr = 0; pr < DPAIRS; ++pr) bsum += fl[lane * DPAIRS + pr];
+    }
   }
 
   // ---- reduce the 4 waves of the block through LDS, one partial record per block (layout of the fp32 kernels:
@@ -443,7 +496,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_bf16_kernel(WgradBfArgs 
     out[i] = (red[i] + red[WG_PART + i]) + (red[2 * WG_PART + i] + red[3 * WG_PART + i]);
 }
 
-template <int HIN, bool XNHWC = false>
+template <int HIN, bool XNHWC = false, bool DYNHWC = false>
 int launch_wgrad_bf16(const WgradBfArgs& a0, float* ws, size_t ws_bytes, int* nblocks_out, hipStream_t st) {
   using G = WgradBfGeom<HIN>;
   constexpr int lds_dwords = 4 * G::WAVE_DWORDS > 4 * WG_PART ? 4 * G::WAVE_DWORDS : 4 * WG_PART;
@@ -458,12 +511,12 @@ int launch_wgrad_bf16(const WgradBfArgs& a0, float* ws, size_t ws_bytes, int* nb
   static bool attr_dev[kMaxDevices] = {};
   bool& attr = attr_dev[drq_device()];
   if (!attr) {
-    const hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16_kernel<HIN, XNHWC>,
+    const hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wgrad_bf16_kernel<HIN, XNHWC, DYNHWC>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_dwords * 4);
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<HIN, XNHWC>), dim3((unsigned)blocks), dim3(256), lds_dwords * 4, st, a);
+  hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<HIN, XNHWC, DYNHWC>), dim3((unsigned)blocks), dim3(256), lds_dwords * 4, st, a);
   DRQ_LAUNCH_CHECK();
   if (nblocks_out) *nblocks_out = (int)blocks;
   return DRQ_OK;
@@ -498,24 +551,34 @@ int drq_conv3x3_fwd_bf16_lay(const void* x, const float* w, const float* bias, v
   return DRQ_EARG;
 }
 
-// mask: bf16 [nb][hout+2][hout+2][32] when mask_nhwc, else fp32 NCHW
-int drq_conv3x3_dgrad_bf16_lay(const float* dy_pad, const float* w, const void* mask, float* dx, int nb, int hout,
-                               long dx_bs, long dx_cs, long dx_rs, long dx_off, int mask_nhwc, hipStream_t st) {
-  if (!dy_pad || !w || !dx || !mask || nb <= 0) return DRQ_EARG;
-  const int hp = hout + 4;
+// lay bits: 1 = dy_pad is bf16 [nb][hout+4][hout+4][32] (zero border), 2 = dx is the interior of a bf16
+// [nb][hout+6][hout+6][32] buffer padded by 2 (the strides are ignored; the border is the caller's), 4 = the mask is bf16
+// [nb][hout+2][hout+2][32]; a clear bit: fp32 NCHW as in drq_conv3x3_dgrad_bf16
+int drq_conv3x3_dgrad_bf16_lay(const void* dy_pad, const float* w, const void* mask, void* dx, int nb, int hout,
+                               long dx_bs, long dx_cs, long dx_rs, long dx_off, int lay, hipStream_t st) {
+  if (!dy_pad || !w || !dx || !mask || nb <= 0 || (lay & ~7)) return DRQ_EARG;
+  const int hp = hout + 4, hin = hout + 2;
+  if (lay & 2) { dx_bs = 16L * (hin + 4) * (hin + 4); dx_cs = 0; dx_rs = 0; dx_off = 0; }
   const size_t yb = (size_t)nb * dx_bs * 4;
-  const size_t mb = (size_t)nb * 32 * (hout + 2) * (hout + 2) * (mask_nhwc ? 2 : 4);
-  if (yb >= (1ull << 31) || mb >= (1ull << 31) || dx_off < 0 || dx_bs <= 0 || (mask_nhwc && ((uintptr_t)mask & 15))) return DRQ_EARG;
-  ConvBfArgs a{dy_pad, w, nullptr, (const float*)mask, dx, dx_bs, dx_cs, dx_rs, dx_off, (unsigned)yb, (unsigned)mb, nb, 0, 1};
-  if (mask_nhwc) {
-    if (hp == 39) return launch_conv_bf16<39, true, 4>(a, st);
-    if (hp == 41) return launch_conv_bf16<41, true, 4>(a, st);
-    if (hp == 43) return launch_conv_bf16<43, true, 4>(a, st);
+  const size_t mb = (size_t)nb * 32 * hin * hin * ((lay & 4) ? 2 : 4);
+  if (yb >= (1ull << 31) || mb >= (1ull << 31) || dx_off < 0 || dx_bs <= 0) return DRQ_EARG;
+  if (((lay & 4) && ((uintptr_t)mask & 15)) || ((lay & 1) && ((uintptr_t)dy_pad & 15)) || ((lay & 2) && ((uintptr_t)dx & 15)))
     return DRQ_EARG;
+  ConvBfArgs a{(const float*)dy_pad, w, nullptr, (const float*)mask, (float*)dx, dx_bs, dx_cs, dx_rs, dx_off, (unsigned)yb,
+               (unsigned)mb, nb, 0, 1, (lay & 2) ? 2 : 0};
+#define DRQ_BF_DGRAD(H)                                         \
+  if (hp == H) {                                                \
+    switch (lay) {                                              \
+      case 0: return launch_conv_bf16<H, true, 0>(a, st);       \
+      case 4: return launch_conv_bf16<H, true, 4>(a, st);       \
+      case 5: return launch_conv_bf16<H, true, 5>(a, st);       \
+      case 6: return launch_conv_bf16<H, true, 6>(a, st);       \
+      case 7: return launch_conv_bf16<H, true, 7>(a, st);       \
+      default: return DRQ_EARG;                                 \
+    }                                                           \
   }
-  if (hp == 39) return launch_conv_bf16<39, true>(a, st);
-  if (hp == 41) return launch_conv_bf16<41, true>(a, st);
-  if (hp == 43) return launch_conv_bf16<43, true>(a, st);
+  DRQ_BF_DGRAD(39) DRQ_BF_DGRAD(41) DRQ_BF_DGRAD(43)
+#undef DRQ_BF_DGRAD
   return DRQ_EARG;
 }
 
@@ -529,9 +592,11 @@ DRQ_API int drq_conv3x3_fwd_bf16_nhwc(const void* x, const float* w, const float
                                   (x_nhwc ? 1 : 0) | (y_nhwc ? 2 : 0), st);
 }
 
-DRQ_API int drq_conv3x3_dgrad_bf16_nhwc(const float* dy_pad, const float* w, const void* mask_nhwc, float* dx, int nb, int hout,
-                                        long dx_bs, long dx_cs, long dx_rs, long dx_off, hipStream_t st) {
-  return drq_conv3x3_dgrad_bf16_lay(dy_pad, w, mask_nhwc, dx, nb, hout, dx_bs, dx_cs, dx_rs, dx_off, 1, st);
+DRQ_API int drq_conv3x3_dgrad_bf16_nhwc(const void* dy_pad, const float* w, const void* mask_nhwc, void* dx, int nb, int hout,
+                                        int dy_nhwc, int dx_nhwc, long dx_bs, long dx_cs, long dx_rs, long dx_off,
+                                        hipStream_t st) {
+  return drq_conv3x3_dgrad_bf16_lay(dy_pad, w, mask_nhwc, dx, nb, hout, dx_bs, dx_cs, dx_rs, dx_off,
+                                    4 | (dy_nhwc ? 1 : 0) | (dx_nhwc ? 2 : 0), st);
 }
 
 DRQ_API int drq_conv3x3_fwd_bf16(const float* x, const float* w, const float* bias, float* y, int nb, int hin, int relu, long y_bs,
@@ -547,22 +612,24 @@ DRQ_API int drq_conv3x3_dgrad_bf16(const float* dy_pad, const float* w, const fl
 }  // extern "C"
 
 // internal (step.hip): partial records only; one reduction launch serves all layers
-// x_nhwc: x is bf16 [nb][hin][hin][32] instead of fp32 NCHW
-int drq_conv3x3_wgrad_partial_bf16_lay(const void* x, const float* dy, int nb, int hin, long dy_bs, long dy_cs, long dy_rs,
-                                       long dy_off, float* part, size_t part_bytes, int* nblocks, int x_nhwc,
+// lay bits: 1 = x is bf16 [nb][hin][hin][32] instead of fp32 NCHW; 2 = dy is the bf16 [nb][hin+2][hin+2][32] buffer
+// zero-padded by 2 (its base; the strides are ignored) instead of an fp32 strided view
+int drq_conv3x3_wgrad_partial_bf16_lay(const void* x, const void* dy, int nb, int hin, long dy_bs, long dy_cs, long dy_rs,
+                                       long dy_off, float* part, size_t part_bytes, int* nblocks, int lay,
                                        hipStream_t st) {
-  if (!x || !dy || !part || !nblocks || nb <= 0 || dy_off < 0 || dy_bs <= 0) return DRQ_EARG;
-  if (((size_t)part & 15) != 0 || (x_nhwc && ((uintptr_t)x & 15))) return DRQ_EARG;
-  WgradBfArgs a{(const float*)x, dy, dy_bs, dy_cs, dy_rs, dy_off, nullptr, nb};
-  if (x_nhwc) {
-    if (hin == 41) return launch_wgrad_bf16<41, true>(a, part, part_bytes, nblocks, st);
-    if (hin == 39) return launch_wgrad_bf16<39, true>(a, part, part_bytes, nblocks, st);
-    if (hin == 37) return launch_wgrad_bf16<37, true>(a, part, part_bytes, nblocks, st);
-    return DRQ_EARG;
+  if (!x || !dy || !part || !nblocks || nb <= 0 || (lay & ~3)) return DRQ_EARG;
+  if (!(lay & 2) && (dy_off < 0 || dy_bs <= 0)) return DRQ_EARG;
+  if (((size_t)part & 15) != 0 || ((lay & 1) && ((uintptr_t)x & 15)) || ((lay & 2) && ((uintptr_t)dy & 15))) return DRQ_EARG;
+  if (lay == 2) return DRQ_EARG;                        // not instantiated: the update never has fp32 x beside bf16 dy
+  WgradBfArgs a{(const float*)x, (const float*)dy, dy_bs, dy_cs, dy_rs, dy_off, nullptr, nb};
+#define DRQ_BF_WGRAD(H)                                                                  \
+  if (hin == H) {                                                                        \
+    if (lay == 3) return launch_wgrad_bf16<H, true, true>(a, part, part_bytes, nblocks, st);  \
+    if (lay == 1) return launch_wgrad_bf16<H, true, false>(a, part, part_bytes, nblocks, st); \
+    return launch_wgrad_bf16<H>(a, part, part_bytes, nblocks, st);                       \
   }
-  if (hin == 41) return launch_wgrad_bf16<41>(a, part, part_bytes, nblocks, st);
-  if (hin == 39) return launch_wgrad_bf16<39>(a, part, part_bytes, nblocks, st);
-  if (hin == 37) return launch_wgrad_bf16<37>(a, part, part_bytes, nblocks, st);
+  DRQ_BF_WGRAD(41) DRQ_BF_WGRAD(39) DRQ_BF_WGRAD(37)
+#undef DRQ_BF_WGRAD
   return DRQ_EARG;
 }
 
@@ -584,12 +651,13 @@ extern "C" DRQ_API int drq_conv3x3_wgrad_bf16(const float* x, const float* dy, f
   return drq_conv3x3_wgrad_reduce_multi(1, parts, &nblk, cins, dws, dbs, st);
 }
 
-extern "C" DRQ_API int drq_conv3x3_wgrad_bf16_nhwc(const void* x_nhwc, const float* dy, float* dw, float* db, int nb, int hin,
-                                                   long dy_bs, long dy_cs, long dy_rs, long dy_off, float* ws,
+extern "C" DRQ_API int drq_conv3x3_wgrad_bf16_nhwc(const void* x_nhwc, const void* dy, float* dw, float* db, int nb, int hin,
+                                                   int dy_nhwc, long dy_bs, long dy_cs, long dy_rs, long dy_off, float* ws,
                                                    size_t ws_bytes, hipStream_t st) {
   if (!dw || !db || !ws) return DRQ_EARG;
   int nblk = 0;
-  const int rc = drq_conv3x3_wgrad_partial_bf16_lay(x_nhwc, dy, nb, hin, dy_bs, dy_cs, dy_rs, dy_off, ws, ws_bytes, &nblk, 1, st);
+  const int rc = drq_conv3x3_wgrad_partial_bf16_lay(x_nhwc, dy, nb, hin, dy_bs, dy_cs, dy_rs, dy_off, ws, ws_bytes, &nblk,
+                                                    dy_nhwc ? 3 : 1, st);
   if (rc != DRQ_OK) return rc;
   const float* parts[1] = {ws};
   const int cins[1] = {32};

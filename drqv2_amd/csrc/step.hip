@@ -88,10 +88,10 @@ int drq_polout_l1_fwd(const float* p2, const float* w3, const float* b3, float* 
 // conv_bf16.hip (internal): the bf16 launches with activations in bf16 [frame][y][x][32] where the flags say so
 int drq_conv3x3_fwd_bf16_lay(const void* x, const float* w, const float* bias, void* y, int nb, int hin, int relu,
                              long y_bs, long y_cs, long y_rs, long y_off, int lay, hipStream_t st);
-int drq_conv3x3_dgrad_bf16_lay(const float* dy_pad, const float* w, const void* mask, float* dx, int nb, int hout,
-                               long dx_bs, long dx_cs, long dx_rs, long dx_off, int mask_nhwc, hipStream_t st);
-int drq_conv3x3_wgrad_partial_bf16_lay(const void* x, const float* dy, int nb, int hin, long dy_bs, long dy_cs, long dy_rs,
-                                       long dy_off, float* part, size_t part_bytes, int* nblocks, int x_nhwc,
+int drq_conv3x3_dgrad_bf16_lay(const void* dy_pad, const float* w, const void* mask, void* dx, int nb, int hout,
+                               long dx_bs, long dx_cs, long dx_rs, long dx_off, int lay, hipStream_t st);
+int drq_conv3x3_wgrad_partial_bf16_lay(const void* x, const void* dy, int nb, int hin, long dy_bs, long dy_cs, long dy_rs,
+                                       long dy_off, float* part, size_t part_bytes, int* nblocks, int lay,
                                        hipStream_t st);
 int drq_conv3x3_wgrad_partial_bf16(const float* x, const float* dy, int nb, int hin, long dy_bs, long dy_cs, long dy_rs,
                                    long dy_off, float* part, size_t part_bytes, int* nblocks, hipStream_t st);
@@ -301,6 +301,9 @@ struct Ctx {
   // bf16 update: the outputs of conv1..conv3 (ACT1..3) are bf16 [frame][y][x][32] (conv_bf16.hip); the features (ACT4),
   // the gradients and the encoder input stay fp32
   bool acts16() const { return s->bf16 && !(s->flags & DRQ_STEP_BF16_FP32_ACTS); }
+  // ... and so are the gradients that pass between the encoder's input-gradient launches (DY3, DY2: zero-padded by 2);
+  // DY4 (written by the trunk's masked scatter) and DY1 (read by conv1's fp32 weight gradient) stay fp32
+  bool grads16() const { return acts16() && !(s->flags & DRQ_STEP_BF16_FP32_GRADS); }
   float* gemm_ws() const { return ws(W_GEMM_WS); }
   size_t gemm_ws_bytes() const { return (size_t)16 * 1024 * 1024 * sizeof(float); }
 
@@ -649,7 +652,8 @@ int phase_conv_backward(const Ctx& c) {
     if (!merged) {
       if (l > 0)
         CK(drq_conv3x3_wgrad_partial_bf16_lay(c.ws(actid[l]), dy, B, hin, 32L * hp * hp, (long)hp * hp, hp, 2L * hp + 2,
-                                              part, quarter, &nblk[l], c.acts16() ? 1 : 0, st));
+                                              part, quarter, &nblk[l],
+                                              (c.acts16() ? 1 : 0) | (c.grads16() && l < 3 ? 2 : 0), st));
       else
         CK(drq_conv3x3_wgrad_partial(c.ws(actid[l]), dy, B, C, hin, 2, 32L * hp * hp, (long)hp * hp, hp, 2L * hp + 2,
                                      part, quarter, &nblk[l], st));
@@ -660,7 +664,9 @@ int phase_conv_backward(const Ctx& c) {
       if (ev && l == 2 && hipEventRecord((hipEvent_t)ev[2], st) != hipSuccess) return DRQ_EARG;
       if (c.bf16())
         CK(drq_conv3x3_dgrad_bf16_lay(dy, c.p(P.enc_w[l]), c.ws(actid[l]), c.ws(dyid[l - 1]), B, hout, 32L * hpi * hpi,
-                                      (long)hpi * hpi, hpi, 2L * hpi + 2, c.acts16() ? 1 : 0, st));
+                                      (long)hpi * hpi, hpi, 2L * hpi + 2,
+                                      (c.acts16() ? 4 : 0) | (c.grads16() && l < 3 ? 1 : 0) | (c.grads16() && l > 1 ? 2 : 0),
+                                      st));
       else
       CK(drq_conv3x3_dgrad_wino_pre(dy, c.p(P.enc_w[l]), c.ws(W_WINO_U) + (2L * (l - 1) + 1) * 16384, c.ws(actid[l]),
                                     c.ws(dyid[l - 1]), B, hout, 32L * hpi * hpi, (long)hpi * hpi, hpi, 2L * hpi + 2, st));

@@ -568,6 +568,12 @@ class StepEngine:
         d.timing_events = self._timing_array      # None, or hipEvent_t pairs for bench.py's roofline
         d.timing_n = self._timing_n if self._timing_array is not None else 0
         d.flags = int(self.step_flags)
+        # the zero borders of the padded gradient buffers lie elsewhere in the bf16 layouts (DrqStep.flags): a workspace
+        # that served the other form is zeroed again
+        mode = (bool(self.bf16), int(self.step_flags) & 12)
+        if getattr(self, "_ws_mode", mode) != mode:
+            ws.zero_()
+        self._ws_mode = mode
         return d
 
     def update(self, obs, action, reward, discount, next_obs, shift_obs, shift_next, noise_critic, noise_actor, std,

@@ -191,20 +191,27 @@ def conv3x3_fwd_bf16_nhwc(x, w, b, relu=True, y_nhwc=True):
     return y
 
 
-def conv3x3_dgrad_bf16_nhwc(dy_pad, w, mask_nhwc):
+def conv3x3_dgrad_bf16_nhwc(dy_pad, w, mask_nhwc, dx_nhwc=False):
+    """dy_pad: fp32 [nb,32,hout+4,hout+4] or bf16 [nb,hout+4,hout+4,32] (zero border of 2); the mask bf16 [nb,hin,hin,32].
+    -> dx fp32 [nb,32,hin,hin], or (dx_nhwc) a zeroed bf16 [nb,hin+4,hin+4,32] buffer with dx in its interior."""
     lib = _lib.load()
-    _need(dy_pad, name="dy_pad"), _need(w, name="w")
-    nb, _, hp, _ = dy_pad.shape
+    _need(w, name="w")
+    dy_nhwc = dy_pad.dtype == torch.bfloat16
+    nb = dy_pad.shape[0]
+    hp = dy_pad.shape[1] if dy_nhwc else dy_pad.shape[2]
     hout = hp - 4
     hin = hout + 2
+    assert dy_pad.is_cuda and dy_pad.is_contiguous()
     assert mask_nhwc.dtype == torch.bfloat16 and tuple(mask_nhwc.shape) == (nb, hin, hin, 32) and mask_nhwc.is_contiguous()
-    dx = torch.empty((nb, 32, hin, hin), device=dy_pad.device, dtype=torch.float32)
-    check(lib.drq_conv3x3_dgrad_bf16_nhwc(ptr(dy_pad), ptr(w), ptr(mask_nhwc), ptr(dx), nb, hout, 32 * hin * hin, hin * hin,
-                                          hin, 0, _stream()), "drq_conv3x3_dgrad_bf16_nhwc")
+    dx = (torch.zeros((nb, hin + 4, hin + 4, 32), device=dy_pad.device, dtype=torch.bfloat16) if dx_nhwc else
+          torch.empty((nb, 32, hin, hin), device=dy_pad.device, dtype=torch.float32))
+    check(lib.drq_conv3x3_dgrad_bf16_nhwc(ptr(dy_pad), ptr(w), ptr(mask_nhwc), ptr(dx), nb, hout, int(dy_nhwc), int(dx_nhwc),
+                                          32 * hin * hin, hin * hin, hin, 0, _stream()), "drq_conv3x3_dgrad_bf16_nhwc")
     return dx
 
 
 def conv3x3_wgrad_bf16_nhwc(x_nhwc, dy):
+    """x bf16 [nb,hin,hin,32]; dy: an fp32 strided view [nb,32,hout,hout] or the padded bf16 [nb,hout+4,hout+4,32] buffer."""
     lib = _lib.load()
     nb, hin, _, _ = x_nhwc.shape
     assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.is_contiguous() and x_nhwc.shape[3] == 32
@@ -212,8 +219,14 @@ def conv3x3_wgrad_bf16_nhwc(x_nhwc, dy):
     db = torch.empty((32,), device=dy.device, dtype=torch.float32)
     nbytes = lib.drq_conv3x3_wgrad_ws_bytes()
     ws = torch.empty((nbytes // 4,), device=dy.device, dtype=torch.float32)
-    check(lib.drq_conv3x3_wgrad_bf16_nhwc(ptr(x_nhwc), dy.data_ptr(), ptr(dw), ptr(db), nb, hin, dy.stride(0), dy.stride(1),
-                                          dy.stride(2), 0, ptr(ws), nbytes, _stream()), "drq_conv3x3_wgrad_bf16_nhwc")
+    if dy.dtype == torch.bfloat16:
+        assert tuple(dy.shape) == (nb, hin + 2, hin + 2, 32) and dy.is_contiguous()
+        check(lib.drq_conv3x3_wgrad_bf16_nhwc(ptr(x_nhwc), ptr(dy), ptr(dw), ptr(db), nb, hin, 1, 0, 0, 0, 0, ptr(ws), nbytes,
+                                              _stream()), "drq_conv3x3_wgrad_bf16_nhwc")
+    else:
+        check(lib.drq_conv3x3_wgrad_bf16_nhwc(ptr(x_nhwc), dy.data_ptr(), ptr(dw), ptr(db), nb, hin, 0, dy.stride(0),
+                                              dy.stride(1), dy.stride(2), 0, ptr(ws), nbytes, _stream()),
+              "drq_conv3x3_wgrad_bf16_nhwc")
     return dw, db
 
 

@@ -108,13 +108,18 @@ int drq_conv3x3_wgrad_bf16(const float* x, const float* dy, float* dw, float* db
  * bf16 [frame][y][x][32 channels], 64 bytes per pixel, 16-byte aligned.  A value stored in that layout is the bf16
  * rounding the entries above apply when they stage it, in the same place of the same sums, so results are identical
  * bit for bit.  fwd: x in that layout when x_nhwc (else fp32 NCHW), y in that layout when y_nhwc (else contiguous fp32
- * NCHW); dgrad: the mask in that layout ([nb][hout+2][hout+2][32]); wgrad: x in that layout. */
+ * NCHW); dgrad: the mask in that layout ([nb][hout+2][hout+2][32]); dy_nhwc: dy_pad is bf16 [nb][hout+4][hout+4][32]
+ * with its zero border; dx_nhwc: dx is the INTERIOR of a bf16 [nb][hout+6][hout+6][32] buffer padded by 2 whose
+ * border the caller keeps zero (the strides are ignored); wgrad: x in that layout; dy_nhwc: dy is the base of such a
+ * padded bf16 [nb][hin+2][hin+2][32] buffer (strides ignored) and db sums the bf16 values. */
 int drq_conv3x3_fwd_bf16_nhwc(const void* x, const float* w, const float* bias, void* y, int nb, int hin, int relu,
                               int x_nhwc, int y_nhwc, drq_stream_t stream);
-int drq_conv3x3_dgrad_bf16_nhwc(const float* dy_pad, const float* w, const void* mask_nhwc, float* dx, int nb, int hout,
-                                long dx_bs, long dx_cs, long dx_rs, long dx_off, drq_stream_t stream);
-int drq_conv3x3_wgrad_bf16_nhwc(const void* x_nhwc, const float* dy, float* dw, float* db, int nb, int hin, long dy_bs,
-                                long dy_cs, long dy_rs, long dy_off, float* ws, size_t ws_bytes, drq_stream_t stream);
+int drq_conv3x3_dgrad_bf16_nhwc(const void* dy_pad, const float* w, const void* mask_nhwc, void* dx, int nb, int hout,
+                                int dy_nhwc, int dx_nhwc, long dx_bs, long dx_cs, long dx_rs, long dx_off,
+                                drq_stream_t stream);
+int drq_conv3x3_wgrad_bf16_nhwc(const void* x_nhwc, const void* dy, float* dw, float* db, int nb, int hin, int dy_nhwc,
+                                long dy_bs, long dy_cs, long dy_rs, long dy_off, float* ws, size_t ws_bytes,
+                                drq_stream_t stream);
 
 /* ---- nn.Linear forward / backward (drqv2.py:74-81,100-111) as one strided, batched GEMM:
  *   C[b][m][n] = epi( sum_k A_b(m,k) * B_b(k,n) ),  epi(v) = relu?(v + bias[n]) * (aux[m][n] > 0)?
@@ -336,11 +341,17 @@ typedef struct {
                               * csrc/gemm3.hip;
                               * DRQ_STEP_BF16_FP32_ACTS (4, bf16 only): the outputs of conv1..conv3 stay fp32 NCHW between
                               * the layers (round 2's storage) instead of bf16 [frame][y][x][32] -- the same update bit
-                              * for bit, more memory traffic.  0 = the production schedule. */
+                              * for bit, more memory traffic;
+                              * DRQ_STEP_BF16_FP32_GRADS (8, bf16 only): the gradients handed from one encoder input
+                              * gradient to the next (of conv3's and conv2's outputs) stay fp32 instead of bf16 in that
+                              * layout -- the same weight gradients bit for bit; the two bias gradients they feed then
+                              * sum unrounded values.  A workspace must be zeroed when these two bits change between
+                              * updates (the zero borders of the padded buffers move).  0 = the production schedule. */
 } DrqStep;
 #define DRQ_STEP_NO_ROW_FUSION 1
 #define DRQ_STEP_NO_GEMM3 2
 #define DRQ_STEP_BF16_FP32_ACTS 4
+#define DRQ_STEP_BF16_FP32_GRADS 8
 
 /* Parameter arena: tensors in parameters() order of encoder, critic, actor, critic_target, each start
  * aligned to 64 floats, each network's segment padded to a multiple of 512 floats (a segment is one optimiser

@@ -84,10 +84,25 @@ def test_conv_bf16_channel_contiguous_layout_is_the_same_arithmetic(ops, hin, nb
     mask = torch.relu(rn(nb, 32, hin, hin))                                            # an activation: zeros and positives
     dx = ops.conv3x3_dgrad(dy_pad, w, mask, bf16=True)
     assert torch.equal(ops.conv3x3_dgrad_bf16_nhwc(dy_pad, w, ops.to_nhwc_bf16(mask)), dx)
+    # ... the incoming gradient in the layout too (bf16, zero border of 2), and the result written into the interior of
+    # a padded bf16 buffer in the layout (what the next input gradient and the weight gradient read)
+    dyn = ops.to_nhwc_bf16(dy_pad)
+    maskn = ops.to_nhwc_bf16(mask)
+    assert torch.equal(ops.conv3x3_dgrad_bf16_nhwc(dyn, w, maskn), dx)
+    for d_in in (dy_pad, dyn):
+        buf = ops.conv3x3_dgrad_bf16_nhwc(d_in, w, maskn, dx_nhwc=True)
+        full = ops.from_nhwc_bf16(buf)
+        assert torch.equal(full[:, :, 2:-2, 2:-2], dx.to(torch.bfloat16).float())
+        full[:, :, 2:-2, 2:-2] = 0
+        assert not bool(full.any())                                                    # the border stays zero
     # weight gradient: the layer input in the layout
     dw, db = ops.conv3x3_wgrad(x, dy_pad[:, :, 2:-2, 2:-2], 1, bf16=True)
     dwn, dbn = ops.conv3x3_wgrad_bf16_nhwc(xn, dy_pad[:, :, 2:-2, 2:-2])
     assert torch.equal(dwn, dw) and torch.equal(dbn, db)
+    # ... and the gradient as the padded bf16 buffer: the same products; the bias gradient sums the rounded values
+    dwp, dbp = ops.conv3x3_wgrad_bf16_nhwc(xn, dyn)
+    assert torch.equal(dwp, dw)
+    assert gerr(dbp, r16(dy).sum((0, 2, 3))) <= 3e-6
 
 
 @pytest.mark.parametrize("n", [2, 70])
@@ -237,11 +252,12 @@ def test_bf16_update_against_fp64_oracle(name):
 def test_bf16_update_activation_storage_does_not_change_the_update(name):
     """The bf16 update keeps the outputs of conv1..conv3 as bf16 [frame][y][x][32]; DRQ_STEP_BF16_FP32_ACTS keeps them
     fp32 NCHW (round 2's storage, rounded when staged).  Same operands in the same sums: two updates from the same
-    state must leave the same parameters, Adam moments and metrics bit for bit."""
+    state must leave the same parameters, Adam moments and metrics bit for bit (the gradients between the layers fp32
+    in both runs: that switch has its own test below)."""
     from tests.test_hip_step import WIDE, make_agent, run_hip
     cfg = WIDE[name]
     outs = []
-    for flags in (0, 4):
+    for flags in (8, 12):
         ag = make_agent(cfg).set_compute_dtype("bf16")
         ag._engine.step_flags = flags
         ms = [run_hip(ag, cfg, u)[0] for u in range(2)]
@@ -252,6 +268,34 @@ def test_bf16_update_activation_storage_does_not_change_the_update(name):
     assert m0 == m1
     for x, y in zip(a0, a1):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("name", ["cheetah_b64", "humanoid_b32"])
+def test_bf16_update_gradient_storage_changes_two_bias_gradients_only(name):
+    """DRQ_STEP_BF16_FP32_GRADS keeps the gradients handed between the encoder's input-gradient launches fp32 instead
+    of bf16 [frame][y][x][32].  The operands of every product are the same, so the first update's metrics and every
+    gradient are identical bit for bit -- except the bias gradients of conv2 and conv3, which sum those gradients' values
+    (rounded in one form, unrounded in the other; sums of cancelling terms: within 1e-2 of their norm, measured 1.6e-3)."""
+    from tests.test_hip_step import WIDE, make_agent, run_hip
+    cfg = WIDE[name]
+    outs = []
+    for flags in (0, 8):
+        ag = make_agent(cfg).set_compute_dtype("bf16")
+        ag._engine.step_flags = flags
+        m = run_hip(ag, cfg, 0)[0]
+        torch.cuda.synchronize()
+        outs.append((m, {n: p.grad.detach().clone() for n, p in ag.encoder.named_parameters()},
+                     ag._engine.grads.clone(), ag._engine.layout["seg"]["enc"]))
+    (m0, e0, g0, seg), (m1, e1, g1, _) = outs
+    assert m0 == m1
+    assert torch.equal(g0[seg[1]:], g1[seg[1]:])                  # critic, actor: everything behind the encoder segment
+    names = list(e0)
+    bias_23 = [n for n in names if n.endswith("bias")][1:3]       # conv2, conv3 (convnet.2, convnet.4)
+    for n in names:
+        if n in bias_23:
+            assert gerr(e0[n], e1[n]) <= 1e-2, (n, gerr(e0[n], e1[n]))
+        else:
+            assert torch.equal(e0[n], e1[n]), n
 
 
 def test_config5_shape_humanoid_batch_2048_fp32_and_bf16():
