@@ -736,13 +736,19 @@ struct QOutBwdArgs {
 
 // Workgroup = 64 columns x 16 row groups (1024 threads).  The per-row scalars dq[B] go to LDS once; the only global
 // stream of the row loop is h, 16 rows of it in flight per thread.
+// CW columns per workgroup, NRG = 1024 / CW row groups.  64 x 16 is the shape for batches up to a few hundred rows
+// (16 workgroups per head at hidden_dim 1024); at batch 2,048 that left 32 workgroups walking 2,048 rows each (60 us per
+// launch): 16 columns x 64 row groups gives four times as many (drq_qout_bwd_cw).  The row-group sums are added in
+// the same fixed order either way (deterministic); the two shapes group them differently (rounding-level).
+template <int CW>
 __global__ __launch_bounds__(1024) void qout_bwd_kernel(QOutBwdArgs a) {
-  extern __shared__ float dql[];            // [B] then 16 x 64 + 16 floats of reduction scratch
+  constexpr int NRG = 1024 / CW;
+  extern __shared__ float dql[];            // [B] then NRG x CW + 64 floats of reduction scratch
   float* s = dql + a.B;
-  float* sb = s + (a.td ? 5 * 1024 : 16 * 64);
+  float* sb = s + (a.td ? 5 * 1024 : 1024);
   const int z = blockIdx.y;
-  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int n = blockIdx.x * 64 + c;
+  const int c = threadIdx.x % CW, rg = threadIdx.x / CW;
+  const int n = blockIdx.x * CW + c;
   const bool nok = n < a.H;
   const int nc = nok ? n : a.H - 1;
   const float* h = a.h[z];
@@ -752,7 +758,7 @@ __global__ __launch_bounds__(1024) void qout_bwd_kernel(QOutBwdArgs a) {
   // dq stage's (a kernel of this size is a chain of dependent memory round trips; every load issued late is one more)
   float hv0[16];
 #pragma unroll
-  for (int u = 0; u < 16; ++u) hv0[u] = h[(long)min(rg + 16 * u, a.B - 1) * a.H + nc];
+  for (int u = 0; u < 16; ++u) hv0[u] = h[(long)min(rg + NRG * u, a.B - 1) * a.H + nc];
   if (a.td == 2) {
     const float *qz = z == 0 ? a.q1 : a.q2, *qo = z == 0 ? a.q2 : a.q1;
     const float g = -a.invB;
@@ -772,13 +778,13 @@ __global__ __launch_bounds__(1024) void qout_bwd_kernel(QOutBwdArgs a) {
   }
   __syncthreads();
   float acc = 0.f, bacc = 0.f;
-  for (int m0 = rg; m0 < a.B; m0 += 16 * 16) {
+  for (int m0 = rg; m0 < a.B; m0 += NRG * 16) {
     float hv[16];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) hv[u] = m0 == rg ? hv0[u] : h[(long)min(m0 + 16 * u, a.B - 1) * a.H + nc];
+    for (int u = 0; u < 16; ++u) hv[u] = m0 == rg ? hv0[u] : h[(long)min(m0 + NRG * u, a.B - 1) * a.H + nc];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-      const int m = m0 + 16 * u;
+      const int m = m0 + NRG * u;
       if (m < a.B) {
         const float d = dql[m];
         bacc += d;
@@ -787,20 +793,20 @@ __global__ __launch_bounds__(1024) void qout_bwd_kernel(QOutBwdArgs a) {
       }
     }
   }
-  s[rg * 64 + c] = acc;
+  s[rg * CW + c] = acc;
   if (c == 0) sb[rg] = bacc;
   __syncthreads();
   if (rg == 0) {
     if (a.dw[z] && nok) {
       float t = 0.f;
 #pragma unroll
-      for (int g2 = 0; g2 < 16; ++g2) t += s[g2 * 64 + c];
+      for (int g2 = 0; g2 < NRG; ++g2) t += s[g2 * CW + c];
       a.dw[z][n] = t;
     }
     if (a.db[z] && blockIdx.x == 0 && c == 0) {
       float t = 0.f;
 #pragma unroll
-      for (int g2 = 0; g2 < 16; ++g2) t += sb[g2];
+      for (int g2 = 0; g2 < NRG; ++g2) t += sb[g2];
       a.db[z][0] = t;
     }
   }
@@ -1244,6 +1250,16 @@ DRQ_API int drq_qout_fwd(int nz, const float* const* h, const float* const* w, c
   return DRQ_OK;
 }
 
+}  // extern "C"
+namespace {
+// 64 columns per workgroup below 1,024 rows, 16 beyond (see qout_bwd_kernel)
+void launch_qout_bwd(const QOutBwdArgs& a, int nz, size_t lds, hipStream_t st) {
+  if (a.B >= 1024) hipLaunchKernelGGL(qout_bwd_kernel<16>, dim3((a.H + 15) / 16, nz), dim3(1024), lds, st, a);
+  else hipLaunchKernelGGL(qout_bwd_kernel<64>, dim3((a.H + 63) / 64, nz), dim3(1024), lds, st, a);
+}
+}  // namespace
+extern "C" {
+
 // dh = (dq w^T) * (h > 0);  dw = dq^T h, db = sum dq when the dw/db arrays are given
 DRQ_API int drq_qout_bwd(int nz, const float* const* dq, const float* const* h, const float* const* w, float* const* dh,
                  float* const* dw, float* const* db, int B, int H, hipStream_t st) {
@@ -1256,9 +1272,9 @@ DRQ_API int drq_qout_bwd(int nz, const float* const* dq, const float* const* h, 
     a.db[z] = db ? db[z] : nullptr;
   }
   a.B = B; a.H = H;
-  const size_t lds = ((size_t)B + 16 * 64 + 16) * sizeof(float);
+  const size_t lds = ((size_t)B + 1024 + 64) * sizeof(float);
   if (lds > 60 * 1024) return DRQ_EARG;
-  hipLaunchKernelGGL(qout_bwd_kernel, dim3((H + 63) / 64, nz), dim3(1024), lds, st, a);
+  launch_qout_bwd(a, nz, lds, st);
   DRQ_LAUNCH_CHECK();
   return DRQ_OK;
 }
@@ -1281,9 +1297,9 @@ int drq_qout_bwd_td(const float* tq1, const float* tq2, const float* q1, const f
   a.B = B; a.H = H;
   a.td = 1; a.tq1 = tq1; a.tq2 = tq2; a.q1 = q1; a.q2 = q2; a.reward = reward; a.discount = discount;
   a.invB = inv_global_B; a.sums = sums;
-  const size_t lds = ((size_t)B + 5 * 1024 + 16) * sizeof(float);      // the sums tree of workgroup (0,0) needs 5 x 1024
+  const size_t lds = ((size_t)B + 5 * 1024 + 64) * sizeof(float);      // the sums tree of workgroup (0,0) needs 5 x 1024
   if (lds > 60 * 1024) return DRQ_EARG;
-  hipLaunchKernelGGL(qout_bwd_kernel, dim3((H + 63) / 64, 2), dim3(1024), lds, st, a);
+  launch_qout_bwd(a, 2, lds, st);
   DRQ_LAUNCH_CHECK();
   return DRQ_OK;
 }
@@ -1302,9 +1318,9 @@ int drq_qout_bwd_actor(const float* q1, const float* q2, const float* act, long 
   a.B = B; a.H = H;
   a.td = 2; a.q1 = q1; a.q2 = q2; a.invB = inv_global_B; a.sums = sums;
   a.act = act; a.lda = lda; a.mu = mu; a.A = A; a.std = std; a.sums_host = sums_host; a.seq = seq;
-  const size_t lds = ((size_t)B + 5 * 1024 + 16) * sizeof(float);
+  const size_t lds = ((size_t)B + 5 * 1024 + 64) * sizeof(float);
   if (lds > 60 * 1024) return DRQ_EARG;
-  hipLaunchKernelGGL(qout_bwd_kernel, dim3((H + 63) / 64, 2), dim3(1024), lds, st, a);
+  launch_qout_bwd(a, 2, lds, st);
   DRQ_LAUNCH_CHECK();
   return DRQ_OK;
 }

@@ -406,8 +406,8 @@ def test_trunk_forward_partials(ops, M, N, K, n):
         assert nerr(got[i], xs[i].double() @ wts[i].double().t()) <= 3e-6
 
 
-@pytest.mark.parametrize("B,H,n", [(256, 1024, 4), (7, 64, 2), (33, 100, 1)])
-def test_qout_fwd_bwd(ops, B, H, n):
+@pytest.mark.parametrize("B,H,n", [(256, 1024, 4), (7, 64, 2), (33, 100, 1), (2048, 1024, 2), (1030, 100, 1)])
+def test_qout_fwd_bwd(ops, B, H, n):     # >= 1,024 rows: the backward kernel's 16-column shape
     hs = [rnd(B, H, seed=i).clamp_min(0) for i in range(n)]
     ws_ = [rnd(H, seed=10 + i, scale=H ** -0.5) for i in range(n)]
     bs = [rnd(1, seed=20 + i) for i in range(n)]
