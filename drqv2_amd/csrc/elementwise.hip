@@ -1062,20 +1062,23 @@ struct PolBwdArgs {
 
 constexpr int kPolMaxA = 32;
 
-// Workgroup = 64 columns of H x 16 row groups.  dpre[B][A] (tiny) is computed once per workgroup into LDS; the only
-// global stream in the row loop is p2, 16 rows of it in flight per thread.
-template <int AMAX>    // action_dim rounded up to 8 / 16 / 32: the per-output loops are unrolled over it
+// Workgroup = CW columns of H x NRG = 1024 / CW row groups.  dpre[B][A] (tiny) is computed once per workgroup into LDS;
+// the only global stream in the row loop is p2, up to 16 rows of it in flight per thread.  CW = 16 (64 workgroups at
+// hidden_dim 1024) is what the update uses: with 64 columns the launch kept 16 CUs busy with 2*A FMAs per row and
+// thread -- 14.6 us at A = 6, 40 us at A = 21 (batch 256), 47 us at A = 12 (batch 512); CW = 64 remains for tiny H.
+template <int AMAX, int CW>    // AMAX: action_dim rounded up to 8 / 16 / 32 (the per-output loops are unrolled over it)
 __global__ __launch_bounds__(1024) void policy_out_bwd_kernel(PolBwdArgs a) {
-  extern __shared__ float dpre[];           // [B][A], then 4 x 16 x 64 floats of reduction scratch
+  constexpr int NRG = 1024 / CW;
+  extern __shared__ float dpre[];           // [B][A], then 4 x NRG x CW = 4096 floats of reduction scratch
   float* sm = dpre + a.B * a.A;
-  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int n = blockIdx.x * 64 + c;
+  const int c = threadIdx.x % CW, rg = threadIdx.x / CW;
+  const int n = blockIdx.x * CW + c;
   const bool nok = n < a.H;
   const int nc = nok ? n : a.H - 1;
   // first batch of p2 rows: independent of dpre, requested before the dpre stage (see qout_bwd_kernel)
   float hv0[16];
 #pragma unroll
-  for (int u = 0; u < 16; ++u) hv0[u] = a.p2[(long)min(rg + 16 * u, a.B - 1) * a.H + nc];
+  for (int u = 0; u < 16; ++u) hv0[u] = a.p2[(long)min(rg + NRG * u, a.B - 1) * a.H + nc];
   for (int i = threadIdx.x; i < a.B * a.A; i += 1024) {
     const int m = i / a.A, j = i - m * a.A;
     const float mv = a.mu[i];
@@ -1097,13 +1100,13 @@ __global__ __launch_bounds__(1024) void policy_out_bwd_kernel(PolBwdArgs a) {
     acc[j] = 0.f;
   }
   __syncthreads();
-  for (int m0 = rg; m0 < a.B; m0 += 16 * 16) {
+  for (int m0 = rg; m0 < a.B; m0 += NRG * 16) {
     float hv[16];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) hv[u] = m0 == rg ? hv0[u] : a.p2[(long)min(m0 + 16 * u, a.B - 1) * a.H + nc];
+    for (int u = 0; u < 16; ++u) hv[u] = m0 == rg ? hv0[u] : a.p2[(long)min(m0 + NRG * u, a.B - 1) * a.H + nc];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-      const int m = m0 + 16 * u;
+      const int m = m0 + NRG * u;
       if (m < a.B) {
         const float* dp = dpre + m * a.A;
         float d = 0.f;
@@ -1119,36 +1122,37 @@ __global__ __launch_bounds__(1024) void policy_out_bwd_kernel(PolBwdArgs a) {
       }
     }
   }
-  // dW3: the 16 row groups of a column are summed in order through LDS, FOUR output rows per barrier pair (one at a
+  // dW3: the row groups of a column are summed in order through LDS, FOUR output rows per barrier pair (one at a
   // time cost two workgroup barriers per action dimension: 21 rounds for humanoid_run)
   for (int j0 = 0; j0 < a.A; j0 += 4) {
 #pragma unroll
     for (int q = 0; q < AMAX; ++q)
-      if (q >= j0 && q < j0 + 4 && q < a.A) sm[((q - j0) * 16 + rg) * 64 + c] = acc[q];
+      if (q >= j0 && q < j0 + 4 && q < a.A) sm[((q - j0) * NRG + rg) * CW + c] = acc[q];
     __syncthreads();
-    if (threadIdx.x < 256) {
-      const int jj = threadIdx.x >> 6;                 // c = threadIdx.x & 63 here as well
+    if (threadIdx.x < 4 * CW) {
+      const int jj = threadIdx.x / CW;                 // c = threadIdx.x % CW here as well
       if (j0 + jj < a.A && nok) {
         float t = 0.f;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) t += sm[(jj * 16 + g) * 64 + c];
+        for (int g = 0; g < NRG; ++g) t += sm[(jj * NRG + g) * CW + c];
         a.dw[(long)(j0 + jj) * a.H + n] = t;
       }
     }
     __syncthreads();
   }
-  // db3: workgroup 0; row group rg sums its rows of dpre[:, c], the 16 partials are added in order
+  // db3: workgroup 0; thread t sums rows t/32, t/32 + 32, ... of dpre[:, t%32], the 32 partials are added in order
   if (blockIdx.x == 0) {
+    const int jb = threadIdx.x & 31, gb = threadIdx.x >> 5;
     float t = 0.f;
-    if (c < a.A)
-      for (int m = rg; m < a.B; m += 16) t += dpre[m * a.A + c];
-    sm[rg * 64 + c] = t;
+    if (jb < a.A)
+      for (int m = gb; m < a.B; m += 32) t += dpre[m * a.A + jb];
+    sm[gb * 32 + jb] = t;
     __syncthreads();
-    if (rg == 0 && c < a.A) {
+    if (gb == 0 && jb < a.A) {
       float tot = 0.f;
 #pragma unroll
-      for (int g = 0; g < 16; ++g) tot += sm[g * 64 + c];
-      a.db[c] = tot;
+      for (int g = 0; g < 32; ++g) tot += sm[g * 32 + jb];
+      a.db[jb] = tot;
     }
   }
 }
@@ -1448,9 +1452,17 @@ int drq_policy_out_bwd(const float* da1, const float* da2, long ld, int col0, co
   const size_t lds = ((size_t)B * A + 4 * 16 * 64) * sizeof(float);
   if (lds > 60 * 1024) return DRQ_EARG;
   PolBwdArgs a{da1, da2, ld, col0, mu, p2, w, dp2, dw, db, B, H, A, part, splitk};
-  if (A <= 8) hipLaunchKernelGGL(policy_out_bwd_kernel<8>, dim3((H + 63) / 64), dim3(1024), lds, st, a);
-  else if (A <= 16) hipLaunchKernelGGL(policy_out_bwd_kernel<16>, dim3((H + 63) / 64), dim3(1024), lds, st, a);
-  else hipLaunchKernelGGL(policy_out_bwd_kernel<32>, dim3((H + 63) / 64), dim3(1024), lds, st, a);
+  if (H >= 256) {          // 16 columns per workgroup
+    const dim3 g((H + 15) / 16);
+    if (A <= 8) hipLaunchKernelGGL((policy_out_bwd_kernel<8, 16>), g, dim3(1024), lds, st, a);
+    else if (A <= 16) hipLaunchKernelGGL((policy_out_bwd_kernel<16, 16>), g, dim3(1024), lds, st, a);
+    else hipLaunchKernelGGL((policy_out_bwd_kernel<32, 16>), g, dim3(1024), lds, st, a);
+  } else {
+    const dim3 g((H + 63) / 64);
+    if (A <= 8) hipLaunchKernelGGL((policy_out_bwd_kernel<8, 64>), g, dim3(1024), lds, st, a);
+    else if (A <= 16) hipLaunchKernelGGL((policy_out_bwd_kernel<16, 64>), g, dim3(1024), lds, st, a);
+    else hipLaunchKernelGGL((policy_out_bwd_kernel<32, 64>), g, dim3(1024), lds, st, a);
+  }
   DRQ_LAUNCH_CHECK();
   return DRQ_OK;
 }
