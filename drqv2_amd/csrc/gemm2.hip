@@ -509,14 +509,16 @@ __global__ __launch_bounds__(256, 1) void trunk_wgrad_kernel(TWArgs g) {
 int drq_trunk_wgrad_ln(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K,
                        float* rowsum, const float* ln_dln, const float* ln_xhat, float* ln_dgamma, float* ln_dbeta,
                        int ln_rows, int ln_F, hipStream_t st) {
-  if (M < 1 || M > 128 || N < 4096 || N % 32 || (K != 128 && K != 256)) return DRQ_EARG;
+  if (M < 1 || M > 128 || N < 4096 || N % 32 || (K != 128 && K != 256 && K != 512)) return DRQ_EARG;
   if (ln_rows > 0 && (!ln_dln || !ln_xhat || !ln_dgamma || !ln_dbeta || ln_F < 1 || ln_F > 256)) return DRQ_EARG;
   const size_t ab = (size_t)K * lda * 4, bb = (size_t)K * ldb * 4;
   if (ab >= (1ull << 31) || bb >= (1ull << 31)) return DRQ_EARG;
   TWArgs g{A, B, C, rowsum, lda, ldb, ldc, M, N, K, (unsigned)ab, (unsigned)bb,
            ln_dln, ln_xhat, ln_dgamma, ln_dbeta, ln_rows > 0 ? ln_rows : 0, ln_F};
   const int blocks = drq_num_cus() + (ln_rows > 0 ? 1 : 0);   // one wave per SIMD (128 + 64 operand registers per lane)
-  if (K == 256) hipLaunchKernelGGL((trunk_wgrad_kernel<8>), dim3(blocks), dim3(256), 0, st, g);
+  // K = 512 (quadruped's batch): dz^T takes 256 of the wave's 512 registers; beyond that the tiled GEMM serves
+  if (K == 512) hipLaunchKernelGGL((trunk_wgrad_kernel<16>), dim3(blocks), dim3(256), 0, st, g);
+  else if (K == 256) hipLaunchKernelGGL((trunk_wgrad_kernel<8>), dim3(blocks), dim3(256), 0, st, g);
   else hipLaunchKernelGGL((trunk_wgrad_kernel<4>), dim3(blocks), dim3(256), 0, st, g);
   DRQ_LAUNCH_CHECK();
   return DRQ_OK;

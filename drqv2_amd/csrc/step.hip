@@ -337,7 +337,7 @@ struct Ctx {
   // The trunk's weight gradient dW = dz^T feat (+ bias gradient) with the LayerNorm parameter gradients of the same
   // trunk riding in the launch (one extra workgroup) when the dedicated kernel takes the shape; `ride` says whether
   // the LayerNorm backward left them out (ln_rides()).
-  bool ln_rides() const { return !bf16() && s->F <= 128 && (s->B == 128 || s->B == 256); }
+  bool ln_rides() const { return !bf16() && s->F <= 128 && (s->B == 128 || s->B == 256 || s->B == 512); }
   int trunk_wgrad(const float* dz, const float* feat, float* gw, float* gb, bool ride, const float* dln,
                   const float* xhat, float* dgamma, float* dbeta) const {
     const int B = s->B, F = s->F;

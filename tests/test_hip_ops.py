@@ -214,7 +214,8 @@ def test_linear_dgrad(ops, M, N, K):
 
 
 @pytest.mark.parametrize("Brows,N,K", [(256, 1024, 1024), (9, 50, 39200), (256, 1, 1024), (31, 1024, 56), (12, 6, 1024),
-                                       (2048, 100, 64), (1030, 1024, 32)])   # >= 1,024 rows: the column sum's 16-column shape
+                                       (2048, 100, 64), (1030, 1024, 32),    # >= 1,024 rows: the column sum's 16-column shape
+                                       (512, 50, 39200), (128, 100, 39200)])  # the trunk kernel's other batch sizes
 def test_linear_wgrad(ops, Brows, N, K):
     dy, x = rnd(Brows, N, seed=1), rnd(Brows, K, seed=2)
     dw, db = ops.linear_wgrad(dy.cuda(), x.cuda())
