@@ -234,6 +234,10 @@ class DrQV2Agent:
                               next_l.contiguous(), f32(sh_o), f32(sh_n), f32(n_c), f32(n_a), stddev, self.stddev_clip,
                               self.critic_target_tau, B_global=n_global)
 
+        # the update is queued: the next batch's host work goes here, beside the GPU (drqv2_amd.replay.BatchIterator)
+        ahead = getattr(replay_iter, "prefetch", None)
+        if ahead is not None:
+            ahead()
         if self.use_tb and self.metrics_on_device:
             inv = 1.0 / (n_global if (eng.pg is None or eng.global_metrics) else (hi - lo))
             if eng._side_busy:           # data parallel with global metrics: the sums exchange runs on a side stream

@@ -37,6 +37,28 @@ class IndexedBatch(tuple):
         return (self.frames[obs_idx].view(shp), action, reward, discount, self.frames[next_idx].view(shp))
 
 
+class BatchIterator:
+    """Endless iterator over device batches with one batch of look-ahead: DrQV2Agent.update() calls prefetch() right
+    after it has queued its kernels, so the next batch's host work (index draw, upload, gather launch) happens while the
+    GPU is busy instead of in front of the next update's first launch (the reference's DataLoader workers run further
+    ahead still, replay_buffer.py:173-190).  The draws and their order are those of plain next() calls."""
+
+    def __init__(self, draw):
+        self._draw = draw
+        self._ahead = None
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        b, self._ahead = self._ahead, None
+        return b if b is not None else self._draw()
+
+    def prefetch(self):
+        if self._ahead is None:
+            self._ahead = self._draw()
+
+
 class DeviceReplay:
     def __init__(self, capacity_steps, obs_shape, action_dim, nstep, discount, device, seed=None, indexed=False):
         self.device = torch.device(device)
@@ -169,7 +191,6 @@ class DeviceReplay:
         return self.gather_indexed(pos) if self.indexed else self.gather(pos)
 
     def __iter__(self):
-        while True:
-            yield self.sample(self.batch_size)
+        return BatchIterator(lambda: self.sample(self.batch_size))
 
     batch_size = 256

@@ -127,11 +127,14 @@ class _Loader:
         self._batch_size = batch_size
 
     def __iter__(self):
+        from drqv2_amd.replay import BatchIterator
         ent = _entry(self._replay_dir)
-        while True:
+
+        def draw():
             while ent["pending"]:
                 self._store.add_episode(ent["pending"].pop(0))
-            yield self._store.sample(self._batch_size)
+            return self._store.sample(self._batch_size)
+        return BatchIterator(draw)
 
 
 def make_replay_loader(replay_dir, max_size, batch_size, num_workers, save_snapshot, nstep, discount, device=None,
