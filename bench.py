@@ -222,6 +222,12 @@ class Runner:
             self.step += 2
         ag.flush()
         self.sync()
+        # the interpreter's cyclic collector stays out of the timed region (a generation-2 pass is a pause of milliseconds,
+        # several updates long; update() itself leaves no cycles behind): collected before, switched back on after
+        import gc
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
         stamps = []
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -231,6 +237,8 @@ class Runner:
         ag.flush()         # data parallel: the last update's deferred Adam steps belong to the timed region
         self.sync()
         dt = time.perf_counter() - t0
+        if gc_was_on:
+            gc.enable()
         per = sorted(1e3 * (b - a) for a, b in zip(stamps[:-1], stamps[1:]))
         pct = (lambda q: per[min(len(per) - 1, int(q * len(per)))]) if per else (lambda q: None)
         if self.world > 1 and self.dp:
