@@ -136,3 +136,23 @@ def test_resume_reloads_reference_named_episode_files(tmp_path):
         st3.add(_Step(t == 4, observation=ep["observation"][t], action=ep["action"][t], reward=ep["reward"][t],
                       discount=ep["discount"][t]))
     assert not list(d2.glob("*.npz"))
+
+
+def test_batch_iterator_look_ahead_keeps_the_order_of_the_draws():
+    """drqv2_amd.replay.BatchIterator: prefetch() draws the next batch early (DrQV2Agent.update() calls it once its
+    kernels are queued); the sequence handed out is that of plain next() calls, and at most one batch is held."""
+    from drqv2_amd.replay import BatchIterator
+    n = [0]
+
+    def draw():
+        n[0] += 1
+        return n[0]
+    it = BatchIterator(draw)
+    assert iter(it) is it
+    assert next(it) == 1
+    it.prefetch()
+    it.prefetch()                      # a second call does not draw again
+    assert n[0] == 2
+    assert next(it) == 2 and next(it) == 3
+    it.prefetch()
+    assert n[0] == 4 and next(it) == 4
