@@ -537,7 +537,8 @@ int drq_conv3x3_fwd_bf16_lay(const void* x, const float* w, const float* bias, v
   const int hout = hin - 2;
   if (lay & 2) { y_bs = 16L * hout * hout; y_cs = 0; y_rs = 0; y_off = 0; }   // 64 bytes per pixel, in floats
   const size_t yb = (size_t)nb * y_bs * 4;
-  if (yb >= (1ull << 31) || y_off < 0 || y_bs <= 0 || ((uintptr_t)x & 15) || ((lay & 2) && ((uintptr_t)y & 15))) return DRQ_EARG;
+  if (yb >= (1ull << 31) || y_off < 0 || y_bs <= 0 || ((lay & 1) && ((uintptr_t)x & 15)) || ((lay & 2) && ((uintptr_t)y & 15)))
+    return DRQ_EARG;
   ConvBfArgs a{(const float*)x, w, bias, nullptr, (float*)y, y_bs, y_cs, y_rs, y_off, (unsigned)yb, 0u, nb, relu, 0};
 #define DRQ_BF_FWD(H)                                            \
   if (hin == H) {                                                \
